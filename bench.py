@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec (fwd+bwd) of ResNet-152 + 6-role GGNN (T=5) at GLOBAL batch 6144,
+bf16, on N MI355X (BASELINE.json metric; config.workload names the configuration).
+
+One "step" = zero_grad -> FCGGNN.forward(img, gt_verb) -> verb_loss + nouns_loss -> backward -> gradient
+all-reduce (N > 1) -> clip_grad_norm_(1) -> Adamax step  (reference order: sr.py:63-83), on synthetic inputs
+already resident in HBM.  Scorer / data loading / .item() logging are outside the step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0, including
+  roofline     -- the dominant kernel (backbone implicit-GEMM convolution): algorithmic FLOPs per launch / average
+                  launch duration, measured with HIP events on the launch stream, against the dense bf16 MFMA peak;
+  cpu_baseline -- the CPU oracle (oracle/, "port") timed on the host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_MFMA_TFLOPS = 157.3
+RESNET_GFLOP = {18: 3.627, 50: 8.174, 152: 23.023}     # per image per pass at 224x224
+
+
+def synthetic_batch(enc, B, res, device, seed_shift=0):
+    """img ~ N(0,1) clamped to the ImageNet-normalised range, uniform verbs, labels uniform in
+    [0,L) on real roles and L (= ignore) on padded roles."""
+    g = torch.Generator(device="cpu").manual_seed(1234 + seed_shift)
+    V, L, R = enc.get_num_verbs(), enc.get_num_labels(), enc.get_max_role_count()
+    verb = torch.randint(0, V, (B,), generator=g)
+    nouns = torch.randint(0, L, (B, 3, R), generator=g)
+    counts = enc.role_counts[verb]
+    nouns[(torch.arange(R)[None, :] >= counts[:, None])[:, None, :].expand(B, 3, R)] = L
+    gd = torch.Generator(device=device).manual_seed(1234 + seed_shift)
+    img = torch.empty((B, 3, res, res), device=device, dtype=torch.float32)
+    chunk = 512
+    for i in range(0, B, chunk):
+        img[i:i + chunk] = torch.randn((min(chunk, B - i), 3, res, res), device=device, generator=gd).clamp_(-2.2, 2.7)
+    return img, verb.to(device), nouns.to(device)
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def cpu_baseline(args):
+    """The oracle's training step (fp32, CPU) on a bounded sample of the same workload."""
+    from oracle.ref_encoder import SyntheticEncoder
+    from oracle.ref_model import RefBackbone, RefFCGGNN, train_step
+    torch.manual_seed(1238)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    enc = SyntheticEncoder()
+    D = 2048 if args.backbone >= 50 else 512
+    net = RefFCGGNN(enc, D, steps=args.T, backbone_factory=lambda: RefBackbone(args.backbone))
+    net.train()
+    opt = torch.optim.Adamax([p for p in net.parameters() if p.requires_grad], lr=0.002)
+    B = args.cpu_batch
+    g = torch.Generator().manual_seed(7)
+    img = torch.randn(B, 3, args.res, args.res, generator=g).clamp_(-2.2, 2.7)
+    verb = torch.randint(0, enc.get_num_verbs(), (B,), generator=g)
+    nouns = torch.randint(0, enc.get_num_labels(), (B, 3, enc.get_max_role_count()), generator=g)
+    log("cpu_baseline: warm-up step (batch %d, %d threads)" % (B, cores))
+    train_step(net, opt, img, verb, nouns)                      # warm-up
+    t0 = time.perf_counter()
+    steps = args.cpu_steps
+    for i in range(steps):
+        train_step(net, opt, img, verb, nouns)
+        log("cpu_baseline: timed step %d/%d done" % (i + 1, steps))
+    dt = time.perf_counter() - t0
+    return {"value": round(B * steps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle (fp32 CPU restatement of reference model.py) full training step, ResNet-%d + 6-role GGNN T=%d, "
+                      "batch %d, %d timed steps after 1 warm-up (%.1f s)" % (args.backbone, args.T, B, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--global-batch", type=int, default=6144)
+    ap.add_argument("--backbone", type=int, default=152)
+    ap.add_argument("--T", type=int, default=5)
+    ap.add_argument("--res", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from situation_recognition_amd import ops, parallel
+    from situation_recognition_amd.imsitu_encoder import imsitu_encoder
+    from situation_recognition_amd.model import FCGGNN
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ops.lib()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    enc = imsitu_encoder.synthetic()                              # V=504, 190 roles, L=2001, R=6
+    torch.manual_seed(1238)                                       # identical replicas on every rank
+    D = 2048 if args.backbone >= 50 else 512
+    net = FCGGNN(enc, D, steps=args.T, backbone=args.backbone, dtype=dtype).to(dev)
+    net.drop_seed_base += rank
+    net.train()
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.Adamax(params, lr=0.002)
+    bucket = parallel.GradBucket(params) if world > 1 else None
+
+    lo, hi = parallel.shard_range(args.global_batch, rank, world)
+    B = hi - lo
+    img, verb, nouns = synthetic_batch(enc, B, args.res, dev, seed_shift=rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pv, pn, pg = net(img, verb)
+        loss = net.verb_loss(pv, verb) + net.nouns_loss(pn, nouns)
+        loss.backward()
+        if bucket is not None:
+            bucket.reduce()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        return loss
+
+    log("model + %d synthetic images per rank resident; warm-up" % B)
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log("warm-up step %d/%d done" % (i + 1, args.warmup))
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss.detach())
+    log("timed region done: %.1f ms/step" % (1000.0 * elapsed / args.steps))
+
+    out = {
+        "metric": "training images/sec (fwd+bwd) at batch 6144, 1/2/4/8 MI355X",
+        "value": round(args.global_batch * args.steps / elapsed, 2),
+        "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "ResNet-%d backbone (x2, frozen, train-mode BN) + 6-role GGNN T=%d + verb/noun classifiers, "
+                               "full training step, global batch %d, %dx%d synthetic images, imSitu-sized vocabulary "
+                               "(504 verbs / 190 roles / 2001 labels)" % (args.backbone, args.T, args.global_batch, args.res, args.res),
+                   "global_batch": args.global_batch, "per_gpu_batch": B, "parallelism": "dp%d" % world,
+                   "final_loss": round(final_loss, 4)},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # Dominant kernel = conv_igemm_kernel (backbone convolutions).  One extra train-mode backbone pass with every
+        # launch bracketed by HIP events on the launch stream; achieved = sum(alg. FLOPs) / sum(durations)
+        # = (average FLOPs per launch) / (average launch duration).
+        ops.PROFILE = []
+        net.convnet_verbs(img)
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        conv = [(e0.elapsed_time(e1) * 1e-3, fl) for tag, e0, e1, fl, _ in prof if tag == "conv"]
+        tsum, fsum = sum(t for t, _ in conv), sum(f for _, f in conv)
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        ach = fsum / tsum / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(ach / peak, 4), "traffic": None,
+                           "kernel": "conv_igemm_kernel (backbone implicit-GEMM convolutions, %d launches per pass)" % len(conv),
+                           "avg_launch_ms": round(1e3 * tsum / len(conv), 4),
+                           "alg_gflop_per_launch": round(fsum / len(conv) / 1e9, 3)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+/* libsrhip -- C ABI of the MI355X (gfx950) hot path of situation-recognition.
+ *
+ * The reference (vFones/situation-recognition) has NO FFI: its hot path is Python
+ * calling torch/torchvision/cuDNN ops.  This ABI is therefore the set
+ * of native entry points that sit beneath the reference's Python class API
+ * (model.resnet / model.GGSNN / model.FCGGNN); each entry cites the reference
+ * lines whose implicit native kernels it replaces.  A reference maintainer binds
+ * it with ctypes.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers to DEVICE memory + sizes; no torch types; never allocates,
+ *     never synchronises, never throws; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = default stream);
+ *   - returns SR_OK (0) or a negative SR_ERR_* code (arguments are validated on
+ *     the host BEFORE anything is launched);
+ *   - `dtype`: SR_F32 (0) or SR_BF16 (1) = storage + MFMA input type of the
+ *     activations/weights; accumulation is always fp32;
+ *   - activations are row-major [rows, channels] = NHWC for images;
+ *   - thread-safe per device (no global mutable state besides a read-only zero page).
+ */
+#ifndef SRHIP_H
+#define SRHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_OK 0
+#define SR_ERR_ARG (-1)      /* bad shape / alignment / null pointer */
+#define SR_ERR_DTYPE (-2)    /* unsupported dtype code */
+#define SR_ERR_LAUNCH (-3)   /* hipLaunch reported an error */
+#define SR_ERR_UNSUPPORTED (-4)
+
+#define SR_F32 0
+#define SR_BF16 1
+
+/* epilogue activation codes for sr_gemm / sr_conv2d */
+#define SR_ACT_NONE 0
+#define SR_ACT_RELU 1
+#define SR_ACT_SIGMOID 2
+#define SR_ACT_TANH 3
+#define SR_ACT_SIGMOID_MUL 4 /* C = s = sigmoid(v); C2 = s * aux1              (GRU reset: r, r*h)   */
+#define SR_ACT_TANH_BLEND 5  /* C2 = c = tanh(v); C = (1-aux2)*aux1 + aux2*c  (GRU candidate+blend) */
+
+int sr_abi_version(void);
+
+/* One (activation, weight) operand pair of a GEMM: contributes A[M,K] . W[N,K]^T. */
+typedef struct sr_kpair {
+  const void* A; /* [M, K] row-major, row stride lda (elements)          */
+  const void* W; /* [N, K] row-major (nn.Linear layout), row stride ldw  */
+  int64_t lda, ldw;
+  int32_t K;     /* multiple of 64 (bf16) / 32 (f32)                      */
+  int32_t _pad;
+} sr_kpair;
+
+/* C[M,N] = epilogue( sum_p A_p . W_p^T + bias_scale*bias + bias2 ) (+ res)
+ *
+ * Replaces the nn.Linear calls of GGSNN.forward (reference model.py:64,75,80-83),
+ * of the classifiers (model.py:152,168) and, in backward, their autograd GEMMs.
+ * Up to 3 operand pairs are summed into one accumulator (W_z n + U_z h in one launch).
+ * out_f32 != 0: C / C2 / res / aux are fp32 even when dtype is bf16.
+ * stats (optional): fp32 [ceil(M/tile_m)][2][N] per-row-tile column sums / sums of
+ * squares of (acc + bias), for train-mode BatchNorm; *stats_tiles receives the
+ * number of row tiles written (may be NULL).
+ */
+typedef struct sr_gemm_args {
+  sr_kpair kp[3];
+  int32_t npairs, M, N, act;
+  void* C;  int64_t ldc;
+  void* C2;                       /* second output (same ld) for the GRU epilogues */
+  const float* bias; const float* bias2; float bias_scale; int32_t out_f32;
+  const void* res; int64_t ldres; /* added BEFORE the activation (residual); same type as C */
+  const void* aux1; const void* aux2; /* same type / ld as C */
+  float* stats;
+} sr_gemm_args;
+int sr_gemm(const sr_gemm_args* a, int dtype, void* stream);
+int sr_gemm_stats_tiles(int M, int N); /* rows of `stats` sr_gemm/sr_conv2d will write */
+
+/* NHWC convolution as implicit GEMM on the same MFMA kernel:
+ * y[b,ho,wo,co] = epilogue( sum_{r,q,c} x[b, ho*s-p+r, wo*s-p+q, c] * w[co,r,q,c] + bias[co] ) (+ res)
+ * Replaces the cuDNN/MIOpen conv2d calls inside torchvision's ResNet forward
+ * (call site: reference model.py:35).  w is [Cout][KH][KW][Cin]; Cin % 64 == 0
+ * (bf16) / 32 (f32).  stem != 0 selects the 7x7/2 stem form: x is the padded
+ * 4-channel image written by sr_stem_prep and w is [Cout][8][32] (sr_stem_pack_weight layout).
+ */
+typedef struct sr_conv_args {
+  const void* x; const void* w;
+  int32_t B, H, W, Cin, Cout, KH, KW, stride, pad, stem;
+  void* y;                 /* [B*Ho*Wo, Cout] */
+  const float* bias;       /* folded BN shift (eval mode) or NULL */
+  const void* res;         /* residual, same shape/type as y, or NULL */
+  int32_t act; int32_t _pad;
+  float* stats;            /* see sr_gemm_args.stats */
+} sr_conv_args;
+int sr_conv2d(const sr_conv_args* a, int dtype, void* stream);
+
+/* fp32 NCHW image [B,3,H,W] -> zero-padded NHWC4 [B, Hp, Wp, 4] (Hp = (H+7)&~1, Wp = (W+7)&~1)
+ * in `dtype`; replaces the layout work cuDNN does for the 7x7 stem (model.py:35). */
+int sr_stem_prep(const float* img, void* out, int B, int H, int W, int dtype, void* stream);
+
+/* Train-mode BatchNorm, phase 2 (reference: model.train() at sr.py:16 puts the frozen
+ * backbone's BatchNorm2d in batch-statistics mode).  Reduces the per-tile partials written by
+ * sr_conv2d, produces scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, and applies the
+ * running-statistics EMA (momentum, unbiased variance).  running_* may be NULL. */
+int sr_bn_finalize(const float* stats, int tiles, int C, int64_t count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps,
+                   float* scale, float* shift, double* scratch, int scratch_rows, void* stream);
+/* scratch: caller-owned fp64 workspace [scratch_rows][2][C] (scratch_rows >= 1; 256 rows use full parallelism)
+ * for the deterministic two-stage reduction of the partials. */
+/* y = [relu]( x*scale[c] + shift[c] (+ res) ), rows x C, in place allowed. */
+int sr_bn_apply(const void* x, const float* scale, const float* shift, const void* res, void* y,
+                int64_t rows, int C, int relu, int dtype, void* stream);
+/* 3x3/2 pad 1 max-pool over NHWC; scale/shift (nullable) are applied (+ReLU) to every input first. */
+int sr_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, const float* scale, const float* shift,
+                    int dtype, void* stream);
+/* global average pool [B, HW, C] -> [B, C] */
+int sr_avgpool(const void* x, void* y, int B, int HW, int C, int dtype, void* stream);
+
+/* node[b*R+r,:] = relu(feat[b,:] * role_emb[role_ids[verb[b]][r],:] * verb_emb[verb[b],:])
+ * (reference model.py:117-144 incl. the encoder lookup imsitu_encoder.py:172-180 done on device).
+ * role_table: int32 [V][R]; feat_relu != 0 applies relu to feat first (unused by the noun path). */
+int sr_node_init_fwd(const void* feat, const float* role_emb, const float* verb_emb, const int64_t* verbs,
+                     const int32_t* role_table, void* node, int B, int R, int D, int dtype, void* stream);
+/* gradients of the above into fp32 d_role_emb [NR+1,D] and d_verb_emb [V,D] (atomic adds; the
+ * padding row NR receives none, as nn.Embedding(padding_idx) does).  feat gets no gradient
+ * (frozen backbone, model.py:17-18). */
+int sr_node_init_bwd(const void* dnode, const void* feat, const float* role_emb, const float* verb_emb,
+                     const int64_t* verbs, const int32_t* role_table, float* d_role_emb, float* d_verb_emb,
+                     int B, int R, int D, int NR, int dtype, void* stream);
+
+/* out[b,i,:] = sum_j A[verb[b]][i][j] * h[b,j,:] (+ add[b,i,:])   (transpose != 0: A^T)
+ * The role-graph message step of GGSNN.forward (model.py:66-77) in its algebraic form, with the
+ * adjacency lookup of imsitu_encoder.py:209-229 done on device from adj_table fp32 [V][R][R]. */
+int sr_ggnn_aggregate(const void* h, const float* adj_table, const int64_t* verbs, const void* add, void* out,
+                      int B, int R, int D, int transpose, int dtype, void* stream);
+
+/* GRU backward, stage 1 (model.py:84,82-83,80 differentiated):
+ *   dc_pre = dh*z*(1-c^2); dz_pre = dh*(c-h)*z*(1-z); dh_acc = dh*(1-z) */
+int sr_gru_bwd1(const void* dh, const void* z, const void* c, const void* h, void* dc_pre, void* dz_pre,
+                void* dh_acc, int64_t n, int dtype, void* stream);
+/* stage 2 (model.py:81,83): dr_pre = drh*h*r*(1-r); dh_acc += drh*r */
+int sr_gru_bwd2(const void* drh, const void* r, const void* h, void* dr_pre, void* dh_acc, int64_t n, int dtype,
+                void* stream);
+
+/* out[C, ld_out] = in[R,C]^T (in row stride ld_in) with optional dtype change; columns R..ld_out of
+ * every output row are zero-filled (pads the reduction dimension of a following dW GEMM);
+ * optional fp32 column sums colsum[C] += scale * sum_r in[r,c] (bias gradients). out may be NULL. */
+int sr_transpose(const void* in, int64_t ld_in, void* out, int64_t R, int64_t C, int64_t ld_out, int in_dtype,
+                 int out_dtype, float* colsum, float colsum_scale, void* stream);
+/* colsum[C] += scale * sum_r in[r,c] */
+int sr_colsum(const void* in, int64_t ld_in, int64_t R, int64_t C, int dtype, float* colsum, float scale, void* stream);
+/* out[r, 0..Cpad) = cast(in[r, 0..C)), zero fill of [C, Cpad); row strides ld_in / ld_out */
+int sr_cast_pad(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C, int64_t Cpad,
+                int in_dtype, int out_dtype, void* stream);
+/* elementwise cast between SR_F32 and SR_BF16 */
+int sr_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);
+/* y = x * keep(i) * 2, keep(i) = bit of a counter-based hash of (seed, i): Dropout(0.5) of the
+ * classifiers (model.py:105-111).  mask_out (uint8, nullable) receives keep(i).  The same call with
+ * x = upstream gradient is the backward. */
+int sr_dropout_half(const void* x, void* y, uint8_t* mask_out, int64_t n, uint64_t seed, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -57,7 +57,7 @@ def _install_torchvision_standin():
 
 
 def _np(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()      # copy: later in-place ops (grad clipping) must not alias
 
 
 def _state(prefix, module):

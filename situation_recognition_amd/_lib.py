@@ -1,0 +1,112 @@
+"""ctypes binding of libsrhip.so (the C ABI declared in include/srhip.h).
+
+There is no fallback: if the shared library is missing or a call returns an error code
+this module raises.  PyTorch is used only to own device memory and streams.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrhip.so")
+
+SR_F32, SR_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SIGMOID_MUL, ACT_TANH_BLEND = range(6)
+_ERR = {-1: "SR_ERR_ARG (bad shape/alignment/null pointer)", -2: "SR_ERR_DTYPE", -3: "SR_ERR_LAUNCH",
+        -4: "SR_ERR_UNSUPPORTED"}
+
+
+class SrError(RuntimeError):
+    pass
+
+
+class KPair(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("lda", C.c_int64), ("ldw", C.c_int64),
+                ("K", C.c_int32), ("_pad", C.c_int32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("kp", KPair * 3), ("npairs", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("act", C.c_int32),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("C2", C.c_void_p),
+                ("bias", C.c_void_p), ("bias2", C.c_void_p), ("bias_scale", C.c_float), ("out_f32", C.c_int32),
+                ("res", C.c_void_p), ("ldres", C.c_int64), ("aux1", C.c_void_p), ("aux2", C.c_void_p),
+                ("stats", C.c_void_p)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("stem", C.c_int32),
+                ("y", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("act", C.c_int32), ("_pad", C.c_int32),
+                ("stats", C.c_void_p)]
+
+
+_P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+SIGNATURES = {
+    "sr_abi_version": [],
+    "sr_gemm": [C.POINTER(GemmArgs), _I, _P],
+    "sr_gemm_stats_tiles": [_I, _I],
+    "sr_conv2d": [C.POINTER(ConvArgs), _I, _P],
+    "sr_stem_prep": [_P, _P, _I, _I, _I, _I, _P],
+    "sr_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P],
+    "sr_bn_apply": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "sr_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P],
+    "sr_avgpool": [_P, _P, _I, _I, _I, _I, _P],
+    "sr_node_init_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sr_node_init_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sr_ggnn_aggregate": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sr_gru_bwd1": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
+    "sr_gru_bwd2": [_P, _P, _P, _P, _P, _L, _I, _P],
+    "sr_transpose": [_P, _L, _P, _L, _L, _L, _I, _I, _P, _F, _P],
+    "sr_colsum": [_P, _L, _L, _L, _I, _P, _F, _P],
+    "sr_cast_pad": [_P, _L, _P, _L, _L, _L, _L, _I, _I, _P],
+    "sr_cast": [_P, _P, _L, _I, _I, _P],
+    "sr_dropout_half": [_P, _P, _P, _L, _U64, _I, _P],
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SrError("libsrhip.so not found at %s -- build it with `python situation_recognition_amd/csrc/build.py` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SrError("%s failed: %s" % (what, _ERR.get(rc, rc)))
+
+
+def dtype_code(t):
+    if t == torch.float32:
+        return SR_F32
+    if t == torch.bfloat16:
+        return SR_BF16
+    raise SrError("unsupported dtype %s (fp32 and bf16 only)" % t)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SrError("situation_recognition_amd runs on an MI355X only: got a %s tensor (no CPU fallback)" % t.device)
+        if t is not None and not t.is_contiguous():
+            raise SrError("non-contiguous tensor passed to a HIP kernel")

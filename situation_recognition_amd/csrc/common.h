@@ -1,0 +1,62 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libsrhip.
+// Wave = 64 lanes everywhere; no other architecture is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/srhip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+#define SR_CHECK_LAUNCH()                                      \
+  do {                                                         \
+    hipError_t e_ = hipGetLastError();                         \
+    if (e_ != hipSuccess) return SR_ERR_LAUNCH;                \
+  } while (0)
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte vector of elements of T (8 bf16 or 4 f32) with float views.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  float4 raw;
+  __device__ __forceinline__ float get(int i) const { return ((const float*)&raw)[i]; }
+  __device__ __forceinline__ void set(int i, float v) { ((float*)&raw)[i] = v; }
+};
+template <> struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  uint4 raw;
+  __device__ __forceinline__ float get(int i) const {
+    uint32_t w = ((const uint32_t*)&raw)[i >> 1];
+    return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+  }
+  __device__ __forceinline__ void set(int i, float v) { ((bf16_t*)&raw)[i] = (bf16_t)v; }
+};
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
+  Vec16<T> v;
+  v.raw = *reinterpret_cast<const decltype(v.raw)*>(p);
+  return v;
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& v) {
+  *reinterpret_cast<decltype(v.raw)*>(p) = v.raw;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  // tanh(x) = 1 - 2/(1+e^{2x}); exact limits at +-inf, abs err ~1e-7
+  return 1.0f - 2.0f / (1.0f + __expf(2.0f * x));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

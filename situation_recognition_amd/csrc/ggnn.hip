@@ -1,0 +1,249 @@
+// Role-graph kernels of the GGNN head (reference model.py:115-155, 59-86) that are not GEMMs:
+// node initialisation (embedding gathers fused with the feature product), the 6x6 adjacency
+// message aggregation, and the elementwise halves of the GRU backward.  All HBM-bound:
+// each lane owns one 16-byte column strip and streams it once.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxR = 8;  // max roles per verb supported (imSitu: 6)
+
+inline unsigned grid_for(long work_items) {
+  long g = (work_items + kThreads - 1) / kThreads;
+  if (g < 1) g = 1;
+  if (g > 256 * 8) g = 256 * 8;
+  return (unsigned)g;
+}
+
+// node[b,r,:] = relu(feat[b,:] * role_emb[role_table[verb_b][r],:] * verb_emb[verb_b,:])
+template <typename T>
+__global__ void node_init_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ role_emb,
+                                     const float* __restrict__ verb_emb, const int64_t* __restrict__ verbs,
+                                     const int32_t* __restrict__ role_table, T* __restrict__ node, int B, int R, int D) {
+  constexpr int N = Vec16<T>::N;
+  const int dv = D / N;
+  const long total = (long)B * dv;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(idx % dv) * N;
+    const long b = idx / dv;
+    const long v = verbs[b];
+    Vec16<T> f = ld16<T>(feat + b * D + d);
+    float fx[N], ve[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { fx[k] = f.get(k); ve[k] = verb_emb[v * D + d + k]; }
+    for (int r = 0; r < R; ++r) {
+      const long rid = role_table[v * R + r];
+      Vec16<T> o;
+#pragma unroll
+      for (int k = 0; k < N; ++k) o.set(k, fmaxf((fx[k] * role_emb[rid * D + d + k]) * ve[k], 0.f));  // model.py:143 order
+      st16<T>(node + (b * R + r) * D + d, o);
+    }
+  }
+}
+
+// y = relu(f*ro*ve):  d ro = g*[y>0]*f*ve ; d ve = sum_r g*[y>0]*f*ro
+template <typename T>
+__global__ void node_init_bwd_kernel(const T* __restrict__ dnode, const T* __restrict__ feat,
+                                     const float* __restrict__ role_emb, const float* __restrict__ verb_emb,
+                                     const int64_t* __restrict__ verbs, const int32_t* __restrict__ role_table,
+                                     float* __restrict__ d_role, float* __restrict__ d_verb, int B, int R, int D, int NR) {
+  constexpr int N = Vec16<T>::N;
+  const int dv = D / N;
+  const long total = (long)B * dv;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(idx % dv) * N;
+    const long b = idx / dv;
+    const long v = verbs[b];
+    Vec16<T> f = ld16<T>(feat + b * D + d);
+    float fx[N], ve[N], dve[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { fx[k] = f.get(k); ve[k] = verb_emb[v * D + d + k]; dve[k] = 0.f; }
+    for (int r = 0; r < R; ++r) {
+      const long rid = role_table[v * R + r];
+      if (rid == NR) continue;  // padding_idx row: value 0, no gradient
+      Vec16<T> g = ld16<T>(dnode + (b * R + r) * D + d);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const float ro = role_emb[rid * D + d + k];
+        const float pre = fx[k] * ro * ve[k];
+        const float gg = pre > 0.f ? g.get(k) : 0.f;
+        dve[k] += gg * fx[k] * ro;
+        atomicAdd(d_role + rid * D + d + k, gg * fx[k] * ve[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) atomicAdd(d_verb + v * D + d + k, dve[k]);
+  }
+}
+
+// out[b,i,:] = sum_j A[i][j] h[b,j,:] (+ add).  One workgroup = one image: the R x R adjacency of
+// the image's verb is staged in LDS once, every lane keeps its R-row column strip in registers.
+template <typename T, int RR>
+__global__ __launch_bounds__(kThreads) void aggregate_kernel(const T* __restrict__ h, const float* __restrict__ adj,
+                                                             const int64_t* __restrict__ verbs, const T* __restrict__ add,
+                                                             T* __restrict__ out, int B, int D, int transpose) {
+  constexpr int N = Vec16<T>::N;
+  __shared__ float A[RR * RR];
+  const int dv = D / N;
+  for (long b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x < RR * RR) {
+      const int i = threadIdx.x / RR, j = threadIdx.x % RR;
+      A[threadIdx.x] = adj[verbs[b] * (RR * RR) + (transpose ? j * RR + i : i * RR + j)];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < dv; c += kThreads) {
+      const long base = b * RR * (long)D + c * N;
+      Vec16<T> hv[RR];
+#pragma unroll
+      for (int j = 0; j < RR; ++j) hv[j] = ld16<T>(h + base + (long)j * D);
+#pragma unroll
+      for (int i = 0; i < RR; ++i) {
+        float s[N];
+        if (add) {
+          Vec16<T> a = ld16<T>(add + base + (long)i * D);
+#pragma unroll
+          for (int k = 0; k < N; ++k) s[k] = a.get(k);
+        } else {
+#pragma unroll
+          for (int k = 0; k < N; ++k) s[k] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < RR; ++j) {
+          const float a = A[i * RR + j];
+#pragma unroll
+          for (int k = 0; k < N; ++k) s[k] += a * hv[j].get(k);
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int k = 0; k < N; ++k) o.set(k, s[k]);
+        st16<T>(out + base + (long)i * D, o);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void gru_bwd1_kernel(const T* __restrict__ dh, const T* __restrict__ z, const T* __restrict__ c,
+                                const T* __restrict__ h, T* __restrict__ dc_pre, T* __restrict__ dz_pre,
+                                T* __restrict__ dh_acc, long nvec) {
+  constexpr int N = Vec16<T>::N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * N;
+    Vec16<T> g = ld16<T>(dh + e), zv = ld16<T>(z + e), cv = ld16<T>(c + e), hv = ld16<T>(h + e), o1, o2, o3;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float gg = g.get(k), zz = zv.get(k), cc = cv.get(k), hh = hv.get(k);
+      o1.set(k, gg * zz * (1.f - cc * cc));
+      o2.set(k, gg * (cc - hh) * zz * (1.f - zz));
+      o3.set(k, gg * (1.f - zz));
+    }
+    st16<T>(dc_pre + e, o1); st16<T>(dz_pre + e, o2); st16<T>(dh_acc + e, o3);
+  }
+}
+
+template <typename T>
+__global__ void gru_bwd2_kernel(const T* __restrict__ drh, const T* __restrict__ r, const T* __restrict__ h,
+                                T* __restrict__ dr_pre, T* __restrict__ dh_acc, long nvec) {
+  constexpr int N = Vec16<T>::N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * N;
+    Vec16<T> g = ld16<T>(drh + e), rv = ld16<T>(r + e), hv = ld16<T>(h + e), acc = ld16<T>(dh_acc + e), o1, o2;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float gg = g.get(k), rr = rv.get(k), hh = hv.get(k);
+      o1.set(k, gg * hh * rr * (1.f - rr));
+      o2.set(k, acc.get(k) + gg * rr);
+    }
+    st16<T>(dr_pre + e, o1); st16<T>(dh_acc + e, o2);
+  }
+}
+
+template <typename T>
+int launch_aggregate(const void* h, const float* adj, const int64_t* verbs, const void* add, void* out, int B, int R, int D,
+                     int transpose, hipStream_t st) {
+  const unsigned g = (unsigned)(B < 256 * 16 ? B : 256 * 16);
+#define AGG(RR)                                                                                                   \
+  case RR:                                                                                                        \
+    hipLaunchKernelGGL((aggregate_kernel<T, RR>), dim3(g), dim3(kThreads), 0, st, (const T*)h, adj, verbs,        \
+                       (const T*)add, (T*)out, B, D, transpose);                                                  \
+    break;
+  switch (R) {
+    AGG(1) AGG(2) AGG(3) AGG(4) AGG(5) AGG(6) AGG(7) AGG(8)
+    default: return SR_ERR_UNSUPPORTED;
+  }
+#undef AGG
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+}  // namespace
+
+#define DT_SWITCH(dtype, EXPR)                        \
+  if ((dtype) == SR_F32) { using T = float; EXPR; }   \
+  else if ((dtype) == SR_BF16) { using T = bf16_t; EXPR; } \
+  else return SR_ERR_DTYPE;
+
+extern "C" int sr_node_init_fwd(const void* feat, const float* role_emb, const float* verb_emb, const int64_t* verbs,
+                                const int32_t* role_table, void* node, int B, int R, int D, int dtype, void* stream) {
+  if (!feat || !role_emb || !verb_emb || !verbs || !role_table || !node || B <= 0 || R <= 0 || D <= 0) return SR_ERR_ARG;
+  const int n = dtype == SR_F32 ? 4 : 8;
+  if (D % n) return SR_ERR_ARG;
+  const long total = (long)B * (D / n);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(node_init_fwd_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                      (const T*)feat, role_emb, verb_emb, verbs, role_table, (T*)node, B, R, D));
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int sr_node_init_bwd(const void* dnode, const void* feat, const float* role_emb, const float* verb_emb,
+                                const int64_t* verbs, const int32_t* role_table, float* d_role_emb, float* d_verb_emb,
+                                int B, int R, int D, int NR, int dtype, void* stream) {
+  if (!dnode || !feat || !role_emb || !verb_emb || !verbs || !role_table || !d_role_emb || !d_verb_emb || B <= 0 || R <= 0 ||
+      D <= 0)
+    return SR_ERR_ARG;
+  const int n = dtype == SR_F32 ? 4 : 8;
+  if (D % n) return SR_ERR_ARG;
+  const long total = (long)B * (D / n);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(node_init_bwd_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                      (const T*)dnode, (const T*)feat, role_emb, verb_emb, verbs, role_table, d_role_emb,
+                                      d_verb_emb, B, R, D, NR));
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int sr_ggnn_aggregate(const void* h, const float* adj_table, const int64_t* verbs, const void* add, void* out,
+                                 int B, int R, int D, int transpose, int dtype, void* stream) {
+  if (!h || !adj_table || !verbs || !out || B <= 0 || R <= 0 || R > kMaxR || D <= 0) return SR_ERR_ARG;
+  const int n = dtype == SR_F32 ? 4 : 8;
+  if (D % n) return SR_ERR_ARG;
+  if (dtype == SR_F32) return launch_aggregate<float>(h, adj_table, verbs, add, out, B, R, D, transpose, (hipStream_t)stream);
+  if (dtype == SR_BF16) return launch_aggregate<bf16_t>(h, adj_table, verbs, add, out, B, R, D, transpose, (hipStream_t)stream);
+  return SR_ERR_DTYPE;
+}
+
+extern "C" int sr_gru_bwd1(const void* dh, const void* z, const void* c, const void* h, void* dc_pre, void* dz_pre,
+                           void* dh_acc, int64_t n, int dtype, void* stream) {
+  if (!dh || !z || !c || !h || !dc_pre || !dz_pre || !dh_acc || n <= 0) return SR_ERR_ARG;
+  const int nv = dtype == SR_F32 ? 4 : 8;
+  if (n % nv) return SR_ERR_ARG;
+  const long nvec = n / nv;
+  DT_SWITCH(dtype, hipLaunchKernelGGL(gru_bwd1_kernel<T>, dim3(grid_for(nvec)), dim3(kThreads), 0, (hipStream_t)stream,
+                                      (const T*)dh, (const T*)z, (const T*)c, (const T*)h, (T*)dc_pre, (T*)dz_pre,
+                                      (T*)dh_acc, nvec));
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int sr_gru_bwd2(const void* drh, const void* r, const void* h, void* dr_pre, void* dh_acc, int64_t n, int dtype,
+                           void* stream) {
+  if (!drh || !r || !h || !dr_pre || !dh_acc || n <= 0) return SR_ERR_ARG;
+  const int nv = dtype == SR_F32 ? 4 : 8;
+  if (n % nv) return SR_ERR_ARG;
+  const long nvec = n / nv;
+  DT_SWITCH(dtype, hipLaunchKernelGGL(gru_bwd2_kernel<T>, dim3(grid_for(nvec)), dim3(kThreads), 0, (hipStream_t)stream,
+                                      (const T*)drh, (const T*)r, (const T*)h, (T*)dr_pre, (T*)dh_acc, nvec));
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}

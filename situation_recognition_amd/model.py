@@ -1,0 +1,534 @@
+"""The reference's model surface (reference model.py: `resnet`, `GGSNN`, `FCGGNN`) executed by the
+HIP kernels of libsrhip.so.  Same class / method / parameter names and state-dict keys as the
+reference, so `sr.py`-style drivers and reference checkpoints work unchanged; the arithmetic runs
+only on an MI355X (no CPU fallback: CPU tensors raise).
+
+What PyTorch does here: owns parameters and device memory, chains the hand-written backward
+functions through autograd, computes the cross-entropy losses and runs the optimizer
+(north_star: "PyTorch-ROCm for autograd/optimizer plumbing").  Everything between the input image
+and the logits -- and its backward -- is a libsrhip kernel.
+
+Knobs the reference hard-codes are constructor arguments: GGNN steps (model.py:60 fixes 4), backbone
+depth (model.py:16 fixes ResNet-152), storage dtype (the reference uses fp16 autocast on CUDA, fp32 on CPU).
+"""
+import itertools
+from math import sqrt
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import SrError
+
+_ARCH = {18: ("basic", (2, 2, 2, 2)), 34: ("basic", (3, 4, 6, 3)), 50: ("bottleneck", (3, 4, 6, 3)),
+         101: ("bottleneck", (3, 4, 23, 3)), 152: ("bottleneck", (3, 8, 36, 3))}
+
+
+def _pad_channels(c):
+    """Channel counts the implicit-GEMM kernel accepts: a power of two >= 64.  Every real ResNet
+    width already is one; narrower test nets are zero-padded (padded channels stay exactly 0)."""
+    p = 64
+    while p < c:
+        p *= 2
+    return p
+
+
+# ----------------------------------------------------------------------------- backbone
+class _Block(nn.Module):
+    """Parameter container for one residual block (torchvision names); never called."""
+
+    def __init__(self, kind, cin, planes, stride):
+        super().__init__()
+        self.kind, self.stride = kind, stride
+        if kind == "bottleneck":
+            cout = planes * 4
+            self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+            self.conv3 = nn.Conv2d(planes, cout, 1, bias=False)
+            self.bn3 = nn.BatchNorm2d(cout)
+        else:
+            cout = planes
+            self.conv1 = nn.Conv2d(cin, planes, 3, stride=stride, padding=1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+        self.cout = cout
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
+
+
+class _ResNetParams(nn.Module):
+    """Parameters/buffers of a torchvision-style ResNet (v1.5: stride on the 3x3), with torchvision's
+    state-dict key names.  The reference obtains this object from `tv.models.resnet152(pretrained=True)`
+    (model.py:16); ImageNet weights are a network fetch, so here the net starts from torchvision's own
+    initialisation (He-normal fan_out convs, BN gamma=1 beta=0) and real weights arrive through
+    `load_state_dict` of a reference checkpoint."""
+
+    def __init__(self, depth, width, blocks):
+        super().__init__()
+        kind, default_blocks = _ARCH[depth]
+        blocks = tuple(blocks) if blocks is not None else default_blocks
+        self.conv1 = nn.Conv2d(3, width, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        cin = width
+        for s in range(4):
+            stage = []
+            for i in range(blocks[s]):
+                blk = _Block(kind, cin, width << s, 2 if (i == 0 and s > 0) else 1)
+                stage.append(blk)
+                cin = blk.cout
+            setattr(self, "layer%d" % (s + 1), nn.Sequential(*stage))
+        self.fc = nn.Linear(cin, 1000)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        raise SrError("_ResNetParams is a parameter container; call the owning `resnet` module")
+
+
+class _ConvBN:
+    """One conv + BatchNorm unit: packs the weights for the implicit-GEMM kernel
+    ([Cout][KH][KW][Cin], channel-padded, storage dtype) and, for eval mode, folds the BN affine of the
+    running statistics into them.  Packs are cached and rebuilt when a parameter changes."""
+
+    def __init__(self, conv, bn, stem=False):
+        self.conv, self.bn, self.stem = conv, bn, stem
+        self.k, self.stride, self.pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.cin_p = 3 if stem else _pad_channels(self.cin)
+        self.cout_p = _pad_channels(self.cout)
+        self._cache = {}
+
+    def _sig(self, with_stats):
+        t = [self.conv.weight, self.bn.weight, self.bn.bias] + ([self.bn.running_mean, self.bn.running_var] if with_stats else [])
+        return tuple((x.data_ptr(), x._version) for x in t)
+
+    def _pack(self, w, dtype):
+        co, ci = w.shape[0], w.shape[1]
+        if self.stem:                                   # [co][r][q*4+c], 8 rows x 8 pixels x 4 channels
+            out = w.new_zeros(self.cout_p, 8, 8, 4)
+            out[:co, :7, :7, :3] = w.permute(0, 2, 3, 1)
+            return out.reshape(self.cout_p, 256).to(dtype).contiguous()
+        out = w.new_zeros(self.cout_p, self.k, self.k, self.cin_p)
+        out[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
+        return out.reshape(self.cout_p, -1).to(dtype).contiguous()
+
+    def _padded(self, t, fill):
+        if t.shape[0] == self.cout_p:
+            return t
+        out = t.new_full((self.cout_p,), fill)
+        out[: t.shape[0]] = t
+        return out
+
+    def raw(self, dtype):
+        key = ("raw", dtype)
+        sig = self._sig(False)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                hit = (sig, self._pack(self.conv.weight.detach().float(), dtype),
+                       self._padded(self.bn.weight.detach().float(), 1.0).contiguous(),
+                       self._padded(self.bn.bias.detach().float(), 0.0).contiguous())
+            self._cache[key] = hit
+        return hit[1], hit[2], hit[3]
+
+    def folded(self, dtype, stats_epoch):
+        key = ("fold", dtype)
+        sig = (self._sig(True), stats_epoch)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != sig:
+            bn = self.bn
+            with torch.no_grad():
+                scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                shift = bn.bias.float() - bn.running_mean.float() * scale
+                w = self.conv.weight.detach().float() * scale.view(-1, 1, 1, 1)
+                hit = (sig, self._pack(w, dtype), self._padded(shift, 0.0).contiguous())
+            self._cache[key] = hit
+        return hit[1], hit[2]
+
+    def running(self):
+        """running_mean / running_var tensors the finalize kernel updates in place (padded copies when
+        the unit is channel-padded; `writeback` copies them home)."""
+        bn = self.bn
+        if self.cout_p == self.cout:
+            return bn.running_mean, bn.running_var, False
+        return self._padded(bn.running_mean, 0.0).contiguous(), self._padded(bn.running_var, 1.0).contiguous(), True
+
+    def writeback(self, rm, rv):
+        with torch.no_grad():
+            self.bn.running_mean.copy_(rm[: self.cout])
+            self.bn.running_var.copy_(rv[: self.cout])
+
+
+class resnet(nn.Module):
+    """reference model.py:8-35 -- frozen ResNet feature extractor ([B,3,H,W] -> [B,2048] pooled features).
+
+    HIP execution: NCHW fp32 image -> padded NHWC4 (`sr_stem_prep`) -> 7x7/2 stem and every
+    1x1 / 3x3 conv as implicit GEMM on MFMA (`sr_conv2d`), NHWC activations in `dtype`.
+      * train mode (the reference trains with `model.train()`, sr.py:16, so the frozen BatchNorms use
+        batch statistics and update their running statistics): conv writes the raw output and per-tile
+        channel sums from the fp32 accumulators, `sr_bn_finalize` reduces them to scale/shift (+ EMA),
+        `sr_bn_apply` normalises (+residual, ReLU) in place;
+      * eval mode: BN is folded into the packed weights; bias, residual add and ReLU run in the conv epilogue.
+    """
+
+    def __init__(self, out_layers, depth=152, width=64, blocks=None, dtype=torch.bfloat16):
+        super().__init__()
+        self.model = _ResNetParams(depth, width, blocks)
+        for p in self.model.parameters():               # model.py:17-18
+            p.requires_grad = False
+        self.out_features = self.model.fc.in_features
+        # model.py:21-31 builds a fresh fc and then discards it for Identity; only the Identity survives
+        self.model.fc = nn.Identity()
+        self.dtype = dtype
+        self.depth = depth
+        self._units = None
+        self._stats_epoch = 0          # bumped whenever a train-mode pass changed running statistics
+        self._pending_tracked = 0      # num_batches_tracked increments not yet written to the buffers
+        self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_counters())
+
+    # -- bookkeeping
+    def _flush_counters(self):
+        if self._pending_tracked:
+            with torch.no_grad():
+                for m in self.model.modules():
+                    if isinstance(m, nn.BatchNorm2d):
+                        m.num_batches_tracked += self._pending_tracked
+            self._pending_tracked = 0
+
+    def _plan(self):
+        if self._units is None:
+            m = self.model
+            stem = _ConvBN(m.conv1, m.bn1, stem=True)
+            blocks = []
+            for s in range(4):
+                for blk in getattr(m, "layer%d" % (s + 1)):
+                    convs = [_ConvBN(blk.conv1, blk.bn1), _ConvBN(blk.conv2, blk.bn2)]
+                    if blk.kind == "bottleneck":
+                        convs.append(_ConvBN(blk.conv3, blk.bn3))
+                    ds = _ConvBN(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+                    blocks.append((convs, ds))
+            self._units = (stem, blocks)
+        return self._units
+
+    # -- execution
+    def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False):
+        dt = self.dtype
+        if not train:
+            w, b = u.folded(dt, self._stats_epoch)
+            y = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=b, res=res, relu=relu, stem_hw=stem_hw)
+            return ops.maxpool3x3s2(y) if pool_after else y
+        w, gamma, beta = u.raw(dt)
+        y, st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, want_stats=True, stem_hw=stem_hw)
+        rm, rv, padded = u.running()
+        scale, shift = ops.bn_finalize(st, y.numel() // u.cout_p, gamma, beta, rm, rv, momentum, u.bn.eps)
+        if padded:
+            u.writeback(rm, rv)
+        if pool_after:                                  # BN + ReLU applied inside the pooling window
+            return ops.maxpool3x3s2(y, scale, shift)
+        return ops.bn_apply(y, scale, shift, res=res, relu=relu, out=y)
+
+    def forward(self, x, bn_updates=1):
+        """`bn_updates`=2 gives the running-statistics state of two consecutive train-mode passes over the
+        same batch in one pass (FCGGNN.forward runs convnet_nouns twice on the same images, model.py:176-178)."""
+        if not x.is_cuda:
+            raise SrError("situation_recognition_amd.resnet runs on an MI355X only (got a CPU tensor; no CPU fallback)")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise SrError("expected an image batch [B,3,H,W]")
+        stem, blocks = self._plan()
+        train = self.training
+        bn0 = self.model.bn1
+        m = bn0.momentum if bn0.momentum is not None else 0.1
+        momentum = 1.0 - (1.0 - m) ** bn_updates
+        with torch.no_grad():
+            H, W = x.shape[2], x.shape[3]
+            xp = ops.stem_prep(x.float().contiguous(), self.dtype)
+            a = self._unit(xp, stem, train, momentum, relu=True, stem_hw=(H, W), pool_after=True)
+            for convs, ds in blocks:
+                idn = a if ds is None else self._unit(a, ds, train, momentum, relu=False)
+                y = a
+                for u in convs[:-1]:
+                    y = self._unit(y, u, train, momentum, relu=True)
+                a = self._unit(y, convs[-1], train, momentum, relu=True, res=idn)
+            feat = ops.avgpool(a)
+        if train:
+            self._stats_epoch += 1
+            self._pending_tracked += bn_updates
+        return feat[:, : self.out_features] if feat.shape[1] != self.out_features else feat
+
+
+# ----------------------------------------------------------------------------- GGNN
+class _Shadow:
+    """Storage-dtype (and transposed) copies of the fp32 master parameters for the MFMA kernels,
+    refreshed when the parameter changes (optimizer step, load_state_dict, .to())."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, p, dtype, transposed=False, pad_to=1):
+        key = (id(p), dtype, transposed, pad_to)
+        sig = (p.data_ptr(), p._version)
+        hit = self._c.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                d = p.detach()
+                if transposed:
+                    t = ops.transpose(d, out_dtype=dtype, pad_to=pad_to)
+                else:
+                    t = d if dtype == torch.float32 else ops.cast(d, dtype)
+            hit = (sig, t)
+            self._c[key] = hit
+        return hit[1]
+
+
+def _kpad(dtype):
+    return 32 if dtype == torch.float32 else 64
+
+
+class _GGNNFunction(torch.autograd.Function):
+    """T steps of model.py:60-84 with a hand-written backward.
+
+    forward per step (4 GEMM launches + 1 aggregate, no standalone elementwise kernel):
+        agg = A.h                                   sr_ggnn_aggregate        (verb path: agg = h)
+        n   = agg W_p^T + (R|1) b_p                 sr_gemm
+        z   = sigmoid(n W_z^T + h U_z^T + b)        sr_gemm, 2 operand pairs, sigmoid epilogue
+        r   = sigmoid(n W_r^T + h U_r^T + b), r*h   sr_gemm, SIGMOID_MUL epilogue
+        c   = tanh(n W_h^T + (r*h) U_h^T + b), h' = (1-z) h + z c     sr_gemm, TANH_BLEND epilogue
+    """
+
+    @staticmethod
+    def forward(ctx, h0, adj, idx, R, verb, steps, shadow, *params):
+        (Wp, bp, Wz, bz, Uz, buz, Wr, br, Ur, bur, Wh, bh, Uh, buh) = params
+        dt = h0.dtype
+        g = lambda p: shadow.get(p, dt)
+        saved = []
+        h = h0.contiguous()
+        for _ in range(steps):
+            agg = h if verb else ops.aggregate(h, adj, idx, R)
+            n = ops.gemm([(agg, g(Wp))], bias=bp, bias_scale=1.0 if verb else float(R))
+            z = ops.gemm([(n, g(Wz)), (h, g(Uz))], bias=bz, bias2=buz, act=ops.ACT_SIGMOID)
+            r, rh = ops.gemm([(n, g(Wr)), (h, g(Ur))], bias=br, bias2=bur, act=ops.ACT_SIGMOID_MUL, aux1=h)
+            h_new, c = ops.gemm([(n, g(Wh)), (rh, g(Uh))], bias=bh, bias2=buh, act=ops.ACT_TANH_BLEND, aux1=h, aux2=z)
+            saved += [h, agg, n, z, r, rh, c]
+            h = h_new
+        ctx.meta = (R, verb, steps, shadow, adj, idx)
+        ctx.save_for_backward(*saved, *params)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        R, verb, steps, shadow, adj, idx = ctx.meta
+        tensors = ctx.saved_tensors
+        saved, params = tensors[: 7 * steps], tensors[7 * steps:]
+        (Wp, bp, Wz, bz, Uz, buz, Wr, br, Ur, bur, Wh, bh, Uh, buh) = params
+        dt = saved[0].dtype
+        kp = _kpad(dt)
+        gT = lambda p: shadow.get(p, dt, transposed=True)
+        D = Wp.shape[0]
+        dev = dh.device
+        gW = {k: torch.zeros(D, D, device=dev, dtype=torch.float32) for k in ("Wp", "Wz", "Uz", "Wr", "Ur", "Wh", "Uh")}
+        gb = {k: torch.zeros(D, device=dev, dtype=torch.float32) for k in ("p", "z", "r", "h")}
+        dh = dh.contiguous()
+        if dh.dtype != dt:
+            dh = ops.cast(dh, dt)
+
+        def acc(name, dyT, xT):
+            ops.gemm([(dyT, xT)], res=gW[name], out=gW[name], out_f32=True)
+
+        for t in reversed(range(steps)):
+            h, agg, n, z, r, rh, c = saved[7 * t: 7 * t + 7]
+            dc, dz, dacc = ops.gru_bwd1(dh, z, c, h)
+            drh = ops.gemm([(dc, gT(Uh))])
+            dr = ops.gru_bwd2(drh, r, h, dacc)                         # dacc += drh * r
+            dn = ops.gemm([(dc, gT(Wh)), (dz, gT(Wz)), (dr, gT(Wr))])
+            dacc = ops.gemm([(dz, gT(Uz)), (dr, gT(Ur))], res=dacc, out=dacc)
+            if verb:
+                dh = ops.gemm([(dn, gT(Wp))], res=dacc)
+            else:
+                dagg = ops.gemm([(dn, gT(Wp))])
+                dh = ops.aggregate(dagg, adj, idx, R, transpose=True, add=dacc)
+            # weight / bias gradients: dW = dY^T X as NT GEMMs over transposed copies; the bias
+            # gradients (column sums) are reduced inside the transpose kernel
+            dcT = ops.transpose(dc, colsum=gb["h"], pad_to=kp)
+            dzT = ops.transpose(dz, colsum=gb["z"], pad_to=kp)
+            drT = ops.transpose(dr, colsum=gb["r"], pad_to=kp)
+            dnT = ops.transpose(dn, colsum=gb["p"], colsum_scale=1.0 if verb else float(R), pad_to=kp)
+            nT, hT, rhT = ops.transpose(n, pad_to=kp), ops.transpose(h, pad_to=kp), ops.transpose(rh, pad_to=kp)
+            aggT = hT if verb else ops.transpose(agg, pad_to=kp)
+            acc("Wh", dcT, nT); acc("Uh", dcT, rhT)
+            acc("Wz", dzT, nT); acc("Uz", dzT, hT)
+            acc("Wr", drT, nT); acc("Ur", drT, hT)
+            acc("Wp", dnT, aggT)
+        grads = (gW["Wp"], gb["p"], gW["Wz"], gb["z"], gW["Uz"], gb["z"].clone(), gW["Wr"], gb["r"], gW["Ur"], gb["r"].clone(),
+                 gW["Wh"], gb["h"], gW["Uh"], gb["h"].clone())
+        return (dh, None, None, None, None, None, None) + grads
+
+
+class GGSNN(nn.Module):
+    """reference model.py:38-86.  `forward(hidden_state, mask=None, verb=False)` keeps the reference
+    signature (mask: [B,R,R] adjacency per image); `steps` generalises the hard-coded 4 (model.py:60)."""
+
+    _ORDER = ("W_p", "W_z", "U_z", "W_r", "U_r", "W_h", "U_h")
+
+    def __init__(self, layersize, steps=4):
+        super().__init__()
+        for n in self._ORDER:                                      # model.py:47-56
+            setattr(self, n, nn.Linear(layersize, layersize))
+        self.steps = steps
+        self._shadow = _Shadow()
+
+    def _params(self):
+        return tuple(itertools.chain.from_iterable((getattr(self, n).weight, getattr(self, n).bias) for n in self._ORDER))
+
+    def run(self, hidden_state, adj_table, verbs, R, verb):
+        if not hidden_state.is_cuda:
+            raise SrError("GGSNN runs on an MI355X only (got a CPU tensor; no CPU fallback)")
+        return _GGNNFunction.apply(hidden_state, adj_table, verbs, R, verb, self.steps, self._shadow, *self._params())
+
+    def forward(self, hidden_state, mask=None, verb=False):
+        if verb:
+            return self.run(hidden_state, None, None, 1, True)
+        B, R = mask.shape[0], mask.shape[1]
+        idx = torch.arange(B, device=mask.device, dtype=torch.int64)
+        return self.run(hidden_state, mask.float().contiguous(), idx, R, False)
+
+
+# ----------------------------------------------------------------------------- head pieces
+class _NodeInitFunction(torch.autograd.Function):
+    """model.py:117-144 (encoder lookup + two embedding gathers + product + ReLU) in one kernel; the backward
+    scatters into the two embedding gradients.  The image features get no gradient (frozen backbone)."""
+
+    @staticmethod
+    def forward(ctx, feat, role_w, verb_w, verbs, role_table):
+        ctx.save_for_backward(feat, role_w, verb_w, verbs, role_table)
+        return ops.node_init_fwd(feat.contiguous(), role_w, verb_w, verbs, role_table)
+
+    @staticmethod
+    def backward(ctx, dnode):
+        feat, role_w, verb_w, verbs, role_table = ctx.saved_tensors
+        d_role, d_verb = torch.zeros_like(role_w), torch.zeros_like(verb_w)
+        dnode = dnode.contiguous()
+        if dnode.dtype != feat.dtype:
+            dnode = ops.cast(dnode, feat.dtype)
+        ops.node_init_bwd(dnode, feat.contiguous(), role_w, verb_w, verbs, role_table, d_role, d_verb)
+        return None, d_role, d_verb, None, None
+
+
+class _ClassifierFunction(torch.autograd.Function):
+    """Dropout(0.5) + Linear (model.py:105-111): counter-hash dropout kernel, MFMA GEMM with fp32 logits."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, shadow, drop_seed):
+        dt = x.dtype
+        xd = ops.dropout_half(x.contiguous(), drop_seed) if drop_seed is not None else x.contiguous()
+        N = W.shape[0]
+        ld = (N + 63) // 64 * 64
+        buf = torch.empty((x.shape[0], ld), device=x.device, dtype=torch.float32)
+        logits = ops.gemm([(xd, shadow.get(W, dt))], bias=b, out=buf[:, :N], out_f32=True)
+        ctx.meta = (shadow, drop_seed, dt)
+        ctx.save_for_backward(xd, W)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dy):
+        shadow, drop_seed, dt = ctx.meta
+        xd, W = ctx.saved_tensors
+        N, kp = W.shape[0], _kpad(dt)
+        if dy.stride(1) != 1:
+            dy = dy.contiguous()
+        db = torch.zeros(N, device=dy.device, dtype=torch.float32)
+        ops.colsum(dy, db)
+        dyp = ops.cast_pad(dy, dt, pad_to=64)                         # [M, Npad] storage dtype, zero padded
+        dx = ops.gemm([(dyp, shadow.get(W, dt, transposed=True, pad_to=64))])
+        if drop_seed is not None:
+            dx = ops.dropout_half(dx, drop_seed)
+        dyT = ops.transpose(dyp, pad_to=kp)                           # [Npad, Mpad]
+        xT = ops.transpose(xd, pad_to=kp)                             # [D, Mpad]
+        dW = ops.gemm([(dyT[:N], xT)], out_f32=True)
+        return dx, dW, db, None, None
+
+
+class FCGGNN(nn.Module):
+    """reference model.py:89-201: verb path and role-graph noun path over two frozen backbones.
+
+    Differences that do not change results: (1) `forward` runs convnet_nouns once and reuses the features for
+    both noun branches (the reference recomputes identical features, model.py:176-178) while giving the BatchNorm
+    running statistics the state two passes would leave; (2) relu() on the pooled verb features (model.py:160) is
+    skipped because a global average of post-ReLU activations is already non-negative.
+    """
+
+    def __init__(self, encoder, D_hidden_state, steps=4, backbone=152, dtype=torch.bfloat16, width=64, blocks=None):
+        super().__init__()
+        self.encoder = encoder
+        self.dtype = dtype
+        nr, nv, nl = encoder.get_num_roles(), encoder.get_num_verbs(), encoder.get_num_labels()
+        self.role_emb = nn.Embedding(nr + 1, D_hidden_state, padding_idx=nr)          # model.py:95-97
+        self.verb_emb = nn.Embedding(nv, D_hidden_state)                                # model.py:98
+        self.convnet_verbs = resnet(nv, backbone, width, blocks, dtype)                 # model.py:100
+        self.convnet_nouns = resnet(nl, backbone, width, blocks, dtype)                 # model.py:101
+        if self.convnet_verbs.out_features != D_hidden_state:
+            raise SrError("D_hidden_state (%d) must equal the backbone feature width (%d)"
+                          % (D_hidden_state, self.convnet_verbs.out_features))
+        self.ggsnn = GGSNN(layersize=D_hidden_state, steps=steps)                       # model.py:103
+        self.verb_classifier = nn.Sequential(nn.Dropout(0.5), nn.Linear(D_hidden_state, nv))     # model.py:105-107
+        self.nouns_classifier = nn.Sequential(nn.Dropout(0.5), nn.Linear(D_hidden_state, nl))    # model.py:109-111
+        self._shadow = _Shadow()
+        self._drop_counter = 0
+        self.drop_seed_base = 0x5eed
+        self._noun_feat_cache = None
+
+    # -- helpers
+    def _drop_seed(self, p):
+        if not self.training or p == 0.0:
+            return None
+        if p != 0.5:
+            raise SrError("only Dropout(0.5) (the reference's value) or p=0 is implemented")
+        self._drop_counter += 1
+        return (self.drop_seed_base * 0x9E3779B1 + self._drop_counter * 0x85EBCA77) & (2 ** 63 - 1)
+
+    def _classify(self, seq, x):
+        lin = seq[1]
+        return _ClassifierFunction.apply(x, lin.weight, lin.bias, self._shadow, self._drop_seed(seq[0].p))
+
+    def _nouns_from_features(self, feat, verbs, batch_size):
+        dev = feat.device
+        role_table, adj_table, _ = self.encoder.device_tables(dev)
+        verbs = verbs.to(device=dev, dtype=torch.int64).contiguous()
+        R = self.encoder.get_max_role_count()
+        node = _NodeInitFunction.apply(feat, self.role_emb.weight, self.verb_emb.weight, verbs, role_table)
+        out = self.ggsnn.run(node, adj_table, verbs, R, False)                          # model.py:151
+        logits = self._classify(self.nouns_classifier, out)                             # model.py:152
+        return logits.reshape(batch_size, R, -1)                                        # model.py:155
+
+    # -- reference surface
+    def predict_nouns(self, img, gt_verb, batch_size):                                  # model.py:115-155
+        feat = self.convnet_nouns(img)
+        return self._nouns_from_features(feat, gt_verb, batch_size)
+
+    def predict_verb(self, img, batch_size):                                            # model.py:158-168
+        feat = self.convnet_verbs(img)
+        out = self.ggsnn.run(feat.reshape(batch_size, -1), None, None, 1, True)
+        return self._classify(self.verb_classifier, out)
+
+    def forward(self, img, gt_verb):                                                    # model.py:172-180
+        batch_size = img.size(0)
+        pred_verb = self.predict_verb(img, batch_size)
+        feat = self.convnet_nouns(img, bn_updates=2)
+        pred_nouns = self._nouns_from_features(feat, torch.argmax(pred_verb, 1), batch_size)
+        gt_pred_nouns = self._nouns_from_features(feat, gt_verb, batch_size)
+        return pred_verb, pred_nouns, gt_pred_nouns
+
+    def verb_loss(self, pred_verb, gt_verb):                                            # model.py:183-187
+        return nn.functional.cross_entropy(pred_verb.float(), gt_verb)
+
+    def nouns_loss(self, pred_nouns, gt_nouns):                                         # model.py:190-201
+        L = self.encoder.get_num_labels()
+        logits = pred_nouns.float().transpose(1, 2)
+        loss = 0
+        for i in range(3):
+            loss = loss + nn.functional.cross_entropy(logits, gt_nouns[:, i], ignore_index=L)
+        return loss

@@ -1,0 +1,263 @@
+"""Tensor-level wrappers over the C ABI (include/srhip.h).  Each function checks shapes on the host,
+allocates outputs with torch (device memory only) and enqueues the HIP kernel on the current stream.
+Nothing here computes on the CPU or with torch operators."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SIGMOID_MUL, ACT_TANH, ACT_TANH_BLEND,  # noqa: F401
+                   check, dtype_code, lib, ptr, require_gpu, stream)
+
+
+# When set to a list, every conv2d / gemm / aggregate launch is bracketed by HIP events on the launch
+# stream and (kernel tag, start, end, algorithmic flops, algorithmic bytes) is appended (bench.py roofline leg).
+PROFILE = None
+
+
+def _timed(tag, flops, nbytes, launch):
+    if PROFILE is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream())
+    rc = launch()
+    e1.record(torch.cuda.current_stream())
+    PROFILE.append((tag, e0, e1, flops, nbytes))
+    return rc
+
+
+def _f32(t, name):
+    if t is not None and t.dtype != torch.float32:
+        raise L.SrError("%s must be fp32" % name)
+    return t
+
+
+def gemm(pairs, N=None, bias=None, bias_scale=1.0, bias2=None, act=ACT_NONE, res=None, aux1=None, aux2=None,
+         out=None, out2=None, out_f32=False, stats=None):
+    """out[M,N] = epilogue(sum_p A_p @ W_p.T + bias_scale*bias + bias2 (+res)).  A_p: [M,K_p], W_p: [>=N, K_p]
+    (nn.Linear layout).  Rows may be strided (last dim contiguous)."""
+    A0, W0 = pairs[0]
+    M = A0.shape[0]
+    N = W0.shape[0] if N is None else N
+    dt = A0.dtype
+    odt = torch.float32 if (out_f32 or dt == torch.float32) else dt
+    a = L.GemmArgs()
+    for i, (A, W) in enumerate(pairs):
+        if A.dtype != dt or W.dtype != dt or A.shape[0] != M or W.shape[0] < N or A.shape[1] != W.shape[1]:
+            raise L.SrError("gemm operand %d: shape/dtype mismatch %s %s" % (i, tuple(A.shape), tuple(W.shape)))
+        if A.stride(1) != 1 or W.stride(1) != 1 or not A.is_cuda or not W.is_cuda:
+            raise L.SrError("gemm operands must be CUDA tensors with contiguous rows")
+        a.kp[i] = L.KPair(A.data_ptr(), W.data_ptr(), A.stride(0), W.stride(0), A.shape[1], 0)
+    if out is None:
+        ldc = (N + 7) // 8 * 8                   # rows stay 16-byte aligned for the vector epilogue
+        buf = torch.empty((M, ldc), device=A0.device, dtype=odt)
+        out = buf[:, :N] if ldc != N else buf
+    if out.dtype != odt or out.shape[0] != M or out.shape[1] != N or out.stride(1) != 1:
+        raise L.SrError("gemm: bad output tensor")
+    two = act in (ACT_SIGMOID_MUL, ACT_TANH_BLEND)
+    if two and out2 is None:
+        out2 = torch.empty_like(out)
+    for t in (res, aux1, aux2, out2):
+        if t is not None and (t.dtype != odt or t.shape != out.shape or t.stride(1) != 1):
+            raise L.SrError("gemm: res/aux/out2 must match the output's shape and dtype")
+    for t in (aux1, aux2, out2):
+        if t is not None and t.stride(0) != out.stride(0):
+            raise L.SrError("gemm: aux/out2 row stride must equal the output's")
+    a.npairs, a.M, a.N, a.act = len(pairs), M, N, act
+    a.C, a.ldc, a.C2 = out.data_ptr(), out.stride(0), ptr(out2)
+    a.bias, a.bias2, a.bias_scale = ptr(_f32(bias, "bias")), ptr(_f32(bias2, "bias2")), float(bias_scale)
+    a.out_f32 = int(odt == torch.float32 and dt != torch.float32)
+    a.res, a.ldres = ptr(res), (res.stride(0) if res is not None else 0)
+    a.aux1, a.aux2, a.stats = ptr(aux1), ptr(aux2), ptr(_f32(stats, "stats"))
+    ktot = sum(A.shape[1] for A, _ in pairs)
+    check(_timed("gemm", 2.0 * M * N * ktot, 0, lambda: lib().sr_gemm(C.byref(a), dtype_code(dt), stream())), "sr_gemm")
+    return (out, out2) if two else out
+
+
+def stats_tiles(M, N):
+    return lib().sr_gemm_stats_tiles(int(M), int(N))
+
+
+def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_stats=False, stem_hw=None):
+    """x: NHWC [B,H,W,Cin] (or, with stem_hw=(H,W), the padded NHWC4 image from stem_prep);
+    w: packed [Cout, KH*KW*Cin] (stem: [Cout, 256]).  Returns y [B,Ho,Wo,Cout] (and stats partials)."""
+    require_gpu(x, w, bias, res)
+    a = L.ConvArgs()
+    B = x.shape[0]
+    if stem_hw is not None:
+        H, W_, Cin = stem_hw[0], stem_hw[1], 3
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W_ + 6 - 7) // 2 + 1
+    else:
+        H, W_, Cin = x.shape[1], x.shape[2], x.shape[3]
+        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W_ + 2 * pad - KH) // stride + 1
+    y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
+    stats = None
+    if want_stats:
+        stats = torch.empty((stats_tiles(B * Ho * Wo, Cout), 2, Cout), device=x.device, dtype=torch.float32)
+    a.x, a.w, a.B, a.H, a.W, a.Cin, a.Cout = x.data_ptr(), w.data_ptr(), B, H, W_, Cin, Cout
+    a.KH, a.KW, a.stride, a.pad, a.stem = KH, KH, stride, pad, int(stem_hw is not None)
+    a.y, a.bias, a.res, a.act, a.stats = y.data_ptr(), ptr(_f32(bias, "bias")), ptr(res), (ACT_RELU if relu else ACT_NONE), ptr(stats)
+    if res is not None and (res.shape != y.shape or res.dtype != y.dtype):
+        raise L.SrError("conv2d: residual shape/dtype mismatch")
+    flops = 2.0 * B * Ho * Wo * Cout * KH * KH * Cin
+    check(_timed("conv", flops, 0, lambda: lib().sr_conv2d(C.byref(a), dtype_code(x.dtype), stream())), "sr_conv2d")
+    return (y, stats) if want_stats else y
+
+
+def stem_prep(img, dtype):
+    require_gpu(img)
+    _f32(img, "img")
+    B, c, H, W_ = img.shape
+    if c != 3:
+        raise L.SrError("stem_prep expects [B,3,H,W]")
+    out = torch.empty((B, (H + 7) & ~1, (W_ + 7) & ~1, 4), device=img.device, dtype=dtype)
+    check(lib().sr_stem_prep(img.data_ptr(), out.data_ptr(), B, H, W_, dtype_code(dtype), stream()), "sr_stem_prep")
+    return out
+
+
+_BN_SCRATCH = {}
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps):
+    require_gpu(stats, gamma, beta, running_mean, running_var)
+    Cc = stats.shape[2]
+    scale = torch.empty(Cc, device=stats.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    key = (stats.device, torch.cuda.current_stream().cuda_stream)
+    scratch = _BN_SCRATCH.get(key)
+    if scratch is None or scratch.shape[2] < Cc:
+        scratch = torch.empty((256, 2, max(Cc, 2048)), device=stats.device, dtype=torch.float64)
+        _BN_SCRATCH[key] = scratch
+    check(lib().sr_bn_finalize(stats.data_ptr(), stats.shape[0], Cc, int(count), gamma.data_ptr(), beta.data_ptr(),
+                               ptr(running_mean), ptr(running_var), float(momentum), float(eps), scale.data_ptr(),
+                               shift.data_ptr(), scratch.data_ptr(), 256, stream()), "sr_bn_finalize")
+    return scale, shift
+
+
+def bn_apply(x, scale, shift, res=None, relu=True, out=None):
+    require_gpu(x, scale, shift, res)
+    out = torch.empty_like(x) if out is None else out
+    Cc = x.shape[-1]
+    check(lib().sr_bn_apply(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), ptr(res), out.data_ptr(), x.numel() // Cc, Cc,
+                            int(relu), dtype_code(x.dtype), stream()), "sr_bn_apply")
+    return out
+
+
+def maxpool3x3s2(x, scale=None, shift=None):
+    require_gpu(x, scale, shift)
+    B, H, W_, Cc = x.shape
+    y = torch.empty((B, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, Cc), device=x.device, dtype=x.dtype)
+    check(lib().sr_maxpool3x3s2(x.data_ptr(), y.data_ptr(), B, H, W_, Cc, ptr(scale), ptr(shift), dtype_code(x.dtype), stream()),
+          "sr_maxpool3x3s2")
+    return y
+
+
+def avgpool(x):
+    require_gpu(x)
+    B, H, W_, Cc = x.shape
+    y = torch.empty((B, Cc), device=x.device, dtype=x.dtype)
+    check(lib().sr_avgpool(x.data_ptr(), y.data_ptr(), B, H * W_, Cc, dtype_code(x.dtype), stream()), "sr_avgpool")
+    return y
+
+
+def node_init_fwd(feat, role_emb, verb_emb, verbs, role_table):
+    require_gpu(feat, role_emb, verb_emb, verbs, role_table)
+    B, D = feat.shape
+    R = role_table.shape[1]
+    if verbs.dtype != torch.int64 or role_table.dtype != torch.int32:
+        raise L.SrError("verbs must be int64 and role_table int32")
+    node = torch.empty((B * R, D), device=feat.device, dtype=feat.dtype)
+    check(lib().sr_node_init_fwd(feat.data_ptr(), _f32(role_emb, "role_emb").data_ptr(), _f32(verb_emb, "verb_emb").data_ptr(),
+                                 verbs.data_ptr(), role_table.data_ptr(), node.data_ptr(), B, R, D, dtype_code(feat.dtype),
+                                 stream()), "sr_node_init_fwd")
+    return node
+
+
+def node_init_bwd(dnode, feat, role_emb, verb_emb, verbs, role_table, d_role_emb, d_verb_emb):
+    require_gpu(dnode, feat, role_emb, verb_emb, verbs, role_table, d_role_emb, d_verb_emb)
+    B, D = feat.shape
+    R = role_table.shape[1]
+    check(lib().sr_node_init_bwd(dnode.data_ptr(), feat.data_ptr(), role_emb.data_ptr(), verb_emb.data_ptr(), verbs.data_ptr(),
+                                 role_table.data_ptr(), _f32(d_role_emb, "d_role_emb").data_ptr(),
+                                 _f32(d_verb_emb, "d_verb_emb").data_ptr(), B, R, D, role_emb.shape[0] - 1,
+                                 dtype_code(feat.dtype), stream()), "sr_node_init_bwd")
+
+
+def aggregate(h, adj_table, verbs, R, transpose=False, add=None, out=None):
+    require_gpu(h, adj_table, verbs, add)
+    M, D = h.shape
+    B = M // R
+    out = torch.empty_like(h) if out is None else out
+    nbytes = (2 + (add is not None)) * M * D * h.element_size() + 4 * B * R * R
+    check(_timed("aggregate", 0, nbytes,
+                 lambda: lib().sr_ggnn_aggregate(h.data_ptr(), _f32(adj_table, "adj_table").data_ptr(), verbs.data_ptr(), ptr(add),
+                                                 out.data_ptr(), B, R, D, int(transpose), dtype_code(h.dtype), stream())),
+          "sr_ggnn_aggregate")
+    return out
+
+
+def gru_bwd1(dh, z, c, h):
+    require_gpu(dh, z, c, h)
+    dc, dz, dacc = torch.empty_like(dh), torch.empty_like(dh), torch.empty_like(dh)
+    check(lib().sr_gru_bwd1(dh.data_ptr(), z.data_ptr(), c.data_ptr(), h.data_ptr(), dc.data_ptr(), dz.data_ptr(),
+                            dacc.data_ptr(), dh.numel(), dtype_code(dh.dtype), stream()), "sr_gru_bwd1")
+    return dc, dz, dacc
+
+
+def gru_bwd2(drh, r, h, dh_acc):
+    require_gpu(drh, r, h, dh_acc)
+    dr = torch.empty_like(drh)
+    check(lib().sr_gru_bwd2(drh.data_ptr(), r.data_ptr(), h.data_ptr(), dr.data_ptr(), dh_acc.data_ptr(), drh.numel(),
+                            dtype_code(drh.dtype), stream()), "sr_gru_bwd2")
+    return dr
+
+
+def transpose(x, out_dtype=None, colsum=None, colsum_scale=1.0, pad_to=1):
+    """[R,C] (rows may be strided) -> [C, Rpad] with Rpad = R rounded up to `pad_to`, zero filled."""
+    require_gpu(colsum)
+    R, Cc = x.shape
+    if x.stride(1) != 1 or not x.is_cuda:
+        raise L.SrError("transpose: rows must be contiguous CUDA memory")
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((Cc, Rp), device=x.device, dtype=out_dtype or x.dtype)
+    check(lib().sr_transpose(x.data_ptr(), x.stride(0), out.data_ptr(), R, Cc, Rp, dtype_code(x.dtype), dtype_code(out.dtype),
+                             ptr(_f32(colsum, "colsum")), float(colsum_scale), stream()), "sr_transpose")
+    return out
+
+
+def colsum(x, acc, scale=1.0):
+    require_gpu(acc)
+    R, Cc = x.shape
+    if x.stride(1) != 1 or not x.is_cuda:
+        raise L.SrError("colsum: rows must be contiguous CUDA memory")
+    check(lib().sr_colsum(x.data_ptr(), x.stride(0), R, Cc, dtype_code(x.dtype), _f32(acc, "acc").data_ptr(), float(scale),
+                          stream()), "sr_colsum")
+    return acc
+
+
+def cast_pad(x, dtype, pad_to=1):
+    """[R,C] (strided rows allowed) -> contiguous [R, Cpad] in `dtype`, zero filled."""
+    R, Cc = x.shape
+    if x.stride(1) != 1 or not x.is_cuda:
+        raise L.SrError("cast_pad: rows must be contiguous CUDA memory")
+    Cp = (Cc + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((R, Cp), device=x.device, dtype=dtype)
+    check(lib().sr_cast_pad(x.data_ptr(), x.stride(0), out.data_ptr(), Cp, R, Cc, Cp, dtype_code(x.dtype), dtype_code(dtype),
+                            stream()), "sr_cast_pad")
+    return out
+
+
+def cast(x, dtype):
+    require_gpu(x)
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    check(lib().sr_cast(x.data_ptr(), out.data_ptr(), x.numel(), dtype_code(x.dtype), dtype_code(dtype), stream()), "sr_cast")
+    return out
+
+
+def dropout_half(x, seed, want_mask=False):
+    require_gpu(x)
+    y = torch.empty_like(x)
+    mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8) if want_mask else None
+    check(lib().sr_dropout_half(x.data_ptr(), y.data_ptr(), ptr(mask), x.numel(), int(seed) & (2 ** 64 - 1),
+                                dtype_code(x.dtype), stream()), "sr_dropout_half")
+    return (y, mask) if want_mask else y

@@ -1,0 +1,240 @@
+"""Kernel-level parity (through the C ABI) against plain fp32 CPU torch ops.
+fp32 storage: tight tolerances.  bf16 storage: inputs are rounded to bf16 first and the
+fp32 reference is computed from the rounded values; tolerance covers bf16 output rounding."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from situation_recognition_amd import ops as o
+    o.lib()
+    return o
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def tol(dtype, ref, k=1.0):
+    m = float(ref.abs().max()) + 1e-6
+    return (2e-5 if dtype == torch.float32 else 1.2e-2) * m * k
+
+
+def close(got, ref, dtype, k=1.0):
+    got = got.float().cpu()
+    err = float((got - ref).abs().max())
+    assert err <= tol(dtype, ref, k), "max err %g > tol %g" % (err, tol(dtype, ref, k))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1000, 72, 320), (64, 504, 512), (37, 40, 64)])
+def test_gemm_plain(ops, dtype, M, N, K):
+    A, W, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2), rnd(N, seed=3)
+    ref = A.float() @ W.float().t() + 2.0 * b
+    out = ops.gemm([(A.cuda(), W.cuda())], bias=b.cuda(), bias_scale=2.0)
+    assert out.shape == (M, N)
+    close(out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_pairs_res_acts_and_f32_out(ops, dtype):
+    M, N = 200, 136
+    A1, A2, A3 = rnd(M, 64, dtype=dtype, seed=1), rnd(M, 128, dtype=dtype, seed=2), rnd(M, 192, dtype=dtype, seed=3)
+    W1, W2, W3 = rnd(N, 64, dtype=dtype, seed=4, scale=.1), rnd(N, 128, dtype=dtype, seed=5, scale=.1), rnd(N, 192, dtype=dtype, seed=6, scale=.1)
+    b1, b2 = rnd(N, seed=7), rnd(N, seed=8)
+    pre = A1.float() @ W1.float().t() + A2.float() @ W2.float().t() + A3.float() @ W3.float().t() + b1 + b2
+    g = lambda t: t.cuda()
+    pairs = [(g(A1), g(W1)), (g(A2), g(W2)), (g(A3), g(W3))]
+    for act, fn in ((ops.ACT_NONE, lambda x: x), (ops.ACT_RELU, torch.relu), (ops.ACT_SIGMOID, torch.sigmoid), (ops.ACT_TANH, torch.tanh)):
+        close(ops.gemm(pairs, bias=g(b1), bias2=g(b2), act=act), fn(pre), dtype)
+    res = rnd(M, N, dtype=dtype, seed=9)
+    close(ops.gemm(pairs, bias=g(b1), bias2=g(b2), act=ops.ACT_RELU, res=g(res)), torch.relu(pre + res.float()), dtype)
+    out = ops.gemm(pairs, bias=g(b1), bias2=g(b2), out_f32=True)
+    assert out.dtype == torch.float32
+    close(out, pre, torch.float32, k=1.0 if dtype == torch.float32 else 1.0)
+    # strided A (a column block of a wider matrix) and an accumulate-into-fp32 residual
+    wide = rnd(M, 256, dtype=dtype, seed=10)
+    acc = rnd(M, N, seed=11)
+    out = ops.gemm([(g(wide)[:, 64:128], g(W1))], res=g(acc), out_f32=True)
+    close(out, wide[:, 64:128].float() @ W1.float().t() + acc, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_gru_epilogues(ops, dtype):
+    M, N, K = 150, 128, 128
+    A, W, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=.2), rnd(N, seed=3)
+    h, z = rnd(M, N, dtype=dtype, seed=4), torch.rand(M, N, generator=torch.Generator().manual_seed(5)).to(dtype)
+    pre = A.float() @ W.float().t() + b
+    r, rh = ops.gemm([(A.cuda(), W.cuda())], bias=b.cuda(), act=ops.ACT_SIGMOID_MUL, aux1=h.cuda())
+    close(r, torch.sigmoid(pre), dtype)
+    close(rh, torch.sigmoid(pre) * h.float(), dtype)
+    hn, c = ops.gemm([(A.cuda(), W.cuda())], bias=b.cuda(), act=ops.ACT_TANH_BLEND, aux1=h.cuda(), aux2=z.cuda())
+    close(c, torch.tanh(pre), dtype)
+    close(hn, (1 - z.float()) * h.float() + z.float() * torch.tanh(pre), dtype)
+
+
+def pack_w(w):  # [Cout,Cin,KH,KW] -> [Cout, KH*KW*Cin]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [
+    (3, 14, 14, 64, 128, 1, 1, 0), (2, 14, 14, 128, 64, 1, 2, 0), (2, 12, 10, 64, 64, 3, 1, 1),
+    (3, 15, 15, 64, 128, 3, 2, 1), (2, 8, 8, 128, 256, 3, 1, 1), (1, 7, 7, 256, 64, 3, 1, 1)])
+def test_conv2d(ops, dtype, B, H, W, Cin, Cout, k, s, p):
+    x = rnd(B, Cin, H, W, dtype=dtype, seed=1)
+    w = rnd(Cout, Cin, k, k, dtype=dtype, seed=2, scale=(Cin * k * k) ** -0.5)
+    ref = F.conv2d(x.float(), w.float(), stride=s, padding=p)            # NCHW
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y, stats = ops.conv2d(xh, pack_w(w).cuda(), Cout, k, s, p, want_stats=True)
+    close(y.permute(0, 3, 1, 2), ref, dtype)
+    n = ref.numel() // Cout
+    s1 = stats[:, 0].sum(0).cpu()
+    s2 = stats[:, 1].sum(0).cpu()
+    assert (s1 / n - ref.mean((0, 2, 3))).abs().max() < 1e-3 * (1 + ref.abs().max())
+    assert (s2 / n - (ref ** 2).mean((0, 2, 3))).abs().max() < 2e-3 * (1 + (ref ** 2).max())
+    # fused epilogue: bias + residual + relu
+    bias, res = rnd(Cout, seed=3), rnd(*ref.shape, dtype=dtype, seed=4)
+    y2 = ops.conv2d(xh, pack_w(w).cuda(), Cout, k, s, p, bias=bias.cuda(), res=res.permute(0, 2, 3, 1).contiguous().cuda(), relu=True)
+    close(y2.permute(0, 3, 1, 2), torch.relu(ref + bias.view(1, -1, 1, 1) + res.float()), dtype)
+
+
+def pack_stem(w):   # [Cout,3,7,7] -> [Cout, 8, 32]: [co][r][q*4+c]
+    Cout = w.shape[0]
+    out = torch.zeros(Cout, 8, 8, 4, dtype=w.dtype)
+    out[:, :7, :7, :3] = w.permute(0, 2, 3, 1)
+    return out.reshape(Cout, 256).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 37, 51), (2, 224, 224)])
+def test_stem_conv(ops, dtype, B, H, W):
+    img = rnd(B, 3, H, W, seed=1)
+    w = rnd(64, 3, 7, 7, dtype=dtype, seed=2, scale=0.1)
+    xp = ops.stem_prep(img.cuda(), dtype)
+    assert xp.shape == (B, (H + 7) & ~1, (W + 7) & ~1, 4)
+    ref_in = img.to(dtype).float()
+    assert torch.equal(xp[:, 3:3 + H, 3:3 + W, :3].float().cpu(), ref_in.permute(0, 2, 3, 1))
+    assert float(xp[:, :3].abs().max()) == 0 and float(xp[..., 3].abs().max()) == 0
+    ref = F.conv2d(ref_in, w.float(), stride=2, padding=3)
+    y = ops.conv2d(xp, pack_stem(w).cuda(), 64, 7, 2, 3, stem_hw=(H, W))
+    close(y.permute(0, 3, 1, 2), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_batchnorm_train_two_phase(ops, dtype):
+    B, H, W, Cin, Cout = 4, 9, 9, 64, 128
+    x = rnd(B, Cin, H, W, dtype=dtype, seed=1)
+    w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=2, scale=0.05)
+    gamma, beta = 0.5 + torch.rand(Cout), rnd(Cout, seed=3, scale=0.2)
+    rm, rv = rnd(Cout, seed=4, scale=0.1), 0.5 + torch.rand(Cout)
+    conv = F.conv2d(x.float(), w.float(), padding=1) + 3.0        # +3: a mean well away from 0
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.relu(F.batch_norm(conv, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5))
+    y, stats = ops.conv2d(x.permute(0, 2, 3, 1).contiguous().cuda(), pack_w(w).cuda(), Cout, 3, 1, 1,
+                          bias=torch.full((Cout,), 3.0).cuda(), want_stats=True)
+    rm_d, rv_d = rm.cuda(), rv.cuda()
+    scale, shift = ops.bn_finalize(stats, B * H * W, gamma.cuda(), beta.cuda(), rm_d, rv_d, 0.1, 1e-5)
+    out = ops.bn_apply(y, scale, shift, relu=True)
+    close(out.permute(0, 3, 1, 2), ref, dtype, k=2.0)
+    assert (rm_d.cpu() - rm_ref).abs().max() < 2e-3
+    assert (rv_d.cpu() - rv_ref).abs().max() < 2e-3
+    res = rnd(B, H, W, Cout, dtype=dtype, seed=9)
+    out2 = ops.bn_apply(y, scale, shift, res=res.cuda(), relu=True)
+    ref2 = F.relu(F.batch_norm(conv, None, None, gamma, beta, training=True, eps=1e-5) + res.float().permute(0, 3, 1, 2))
+    close(out2.permute(0, 3, 1, 2), ref2, dtype, k=2.0)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_pools(ops, dtype):
+    x = rnd(3, 64, 13, 17, dtype=dtype, seed=1)
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    close(ops.maxpool3x3s2(xh).permute(0, 3, 1, 2), F.max_pool2d(x.float(), 3, 2, 1), dtype)
+    sc, sh = rnd(64, seed=2), rnd(64, seed=3)
+    ref = F.max_pool2d(F.relu(x.float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 3, 2, 1)
+    close(ops.maxpool3x3s2(xh, sc.cuda(), sh.cuda()).permute(0, 3, 1, 2), ref, dtype)
+    close(ops.avgpool(xh), x.float().mean((2, 3)), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_node_init_and_aggregate(ops, dtype):
+    B, R, D, V, NR = 9, 6, 128, 7, 11
+    g = torch.Generator().manual_seed(0)
+    feat = rnd(B, D, dtype=dtype, seed=1)
+    role_emb = rnd(NR + 1, D, seed=2); role_emb[NR] = 0
+    verb_emb = rnd(V, D, seed=3)
+    verbs = torch.randint(0, V, (B,), generator=g)
+    counts = torch.randint(1, R + 1, (V,), generator=g)
+    table = torch.full((V, R), NR, dtype=torch.int32)
+    adj = torch.zeros(V, R, R)
+    for v in range(V):
+        k = int(counts[v])
+        table[v, :k] = torch.randperm(NR, generator=g)[:k].int()
+        adj[v, :k, :k] = 1; adj[v].fill_diagonal_(0)
+        for p_ in range(k, R): adj[v, p_, p_] = 1
+    adj += 0.25 * torch.rand(V, R, R, generator=g)          # asymmetric: catches a transposed read
+    re, ve = role_emb.clone().requires_grad_(True), verb_emb.clone().requires_grad_(True)
+    ref = F.relu(feat.float()[:, None] * re[table.long()[verbs]] * ve[verbs][:, None]).reshape(B * R, D)
+    node = ops.node_init_fwd(feat.cuda(), role_emb.cuda(), verb_emb.cuda(), verbs.cuda(), table.cuda())
+    close(node, ref.detach(), dtype)
+    dn = rnd(B * R, D, dtype=dtype, seed=5)
+    ref.backward(dn.float())
+    dre, dve = torch.zeros(NR + 1, D).cuda(), torch.zeros(V, D).cuda()
+    ops.node_init_bwd(dn.cuda(), feat.cuda(), role_emb.cuda(), verb_emb.cuda(), verbs.cuda(), table.cuda(), dre, dve)
+    re.grad[NR] = 0                                            # padding_idx semantics
+    close(dre, re.grad, torch.float32, k=20)
+    close(dve, ve.grad, torch.float32, k=20)
+    h = rnd(B * R, D, dtype=dtype, seed=6)
+    A = adj[verbs]
+    close(ops.aggregate(h.cuda(), adj.cuda(), verbs.cuda(), R), torch.bmm(A, h.float().view(B, R, D)).view(B * R, D), dtype)
+    add = rnd(B * R, D, dtype=dtype, seed=7)
+    close(ops.aggregate(h.cuda(), adj.cuda(), verbs.cuda(), R, transpose=True, add=add.cuda()),
+          torch.bmm(A.transpose(1, 2), h.float().view(B, R, D)).view(B * R, D) + add.float(), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gru_backward_halves(ops, dtype):
+    n = (77, 64)
+    dh, c, h = rnd(*n, dtype=dtype, seed=1), torch.tanh(rnd(*n, seed=2)).to(dtype), rnd(*n, dtype=dtype, seed=3)
+    z, r = torch.sigmoid(rnd(*n, seed=4)).to(dtype), torch.sigmoid(rnd(*n, seed=5)).to(dtype)
+    drh = rnd(*n, dtype=dtype, seed=6)
+    f = lambda t: t.float()
+    dc, dz, dacc = ops.gru_bwd1(dh.cuda(), z.cuda(), c.cuda(), h.cuda())
+    close(dc, f(dh) * f(z) * (1 - f(c) ** 2), dtype)
+    close(dz, f(dh) * (f(c) - f(h)) * f(z) * (1 - f(z)), dtype)
+    close(dacc, f(dh) * (1 - f(z)), dtype)
+    acc0 = dacc.clone()
+    dr = ops.gru_bwd2(drh.cuda(), r.cuda(), h.cuda(), dacc)
+    close(dr, f(drh) * f(h) * f(r) * (1 - f(r)), dtype)
+    close(dacc, acc0.float().cpu() + f(drh) * f(r), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_transpose_colsum_cast_dropout(ops, dtype):
+    x = rnd(333, 200, dtype=dtype, seed=1)
+    cs = torch.ones(200).cuda()
+    t = ops.transpose(x.cuda(), colsum=cs, colsum_scale=3.0)
+    assert torch.equal(t.cpu(), x.t().contiguous())
+    close(cs, 1 + 3.0 * x.float().sum(0), torch.float32, k=10)
+    t2 = ops.transpose(rnd(130, 70, seed=2).cuda(), out_dtype=torch.bfloat16)
+    assert torch.equal(t2.cpu(), rnd(130, 70, seed=2).t().contiguous().to(torch.bfloat16))
+    cs2 = torch.zeros(200).cuda()
+    ops.colsum(x.cuda(), cs2, 1.0)
+    close(cs2, x.float().sum(0), torch.float32, k=10)
+    assert torch.equal(ops.cast(x.cuda(), torch.float32).cpu(), x.float())
+    xx = rnd(4096, 64, dtype=dtype, seed=3)
+    y, m = ops.dropout_half(xx.cuda(), 1234, want_mask=True)
+    y2 = ops.dropout_half(xx.cuda(), 1234)
+    assert torch.equal(y, y2)
+    assert torch.equal(y.cpu().float(), xx.float() * 2 * m.cpu().float())
+    assert 0.48 < float(m.float().mean()) < 0.52
+    assert not torch.equal(m, ops.dropout_half(xx.cuda(), 99, want_mask=True)[1])

@@ -111,7 +111,17 @@ def test_g5_one_training_step():
     net.verb_classifier[0].p = 0.0
     net.nouns_classifier[0].p = 0.0
     opt = torch.optim.Adamax([p for p in net.parameters() if p.requires_grad], lr=0.002)
-    r = train_step(net, opt, torch.from_numpy(g["img"]), torch.from_numpy(g["gt_verb"]), torch.from_numpy(g["gt_nouns"]))
+    img, verb, nouns = torch.from_numpy(g["img"]), torch.from_numpy(g["gt_verb"]), torch.from_numpy(g["gt_nouns"])
+    # unclipped gradients first (a separate backward on a copy of the net)
+    import copy
+    twin = copy.deepcopy(net)
+    pv, pn, _ = twin(img, verb)
+    (twin.verb_loss(pv, verb) + twin.nouns_loss(pn, nouns)).backward()
+    for k, p in twin.named_parameters():
+        if p.requires_grad:
+            ref = g["grad/" + k]
+            assert np.abs(p.grad.numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), k
+    r = train_step(net, opt, img, verb, nouns)
     assert abs(float(r["verb_loss"]) - float(g["verb_loss"])) < 1e-5
     assert abs(float(r["nouns_loss"]) - float(g["nouns_loss"])) < 1e-4
     assert abs(float(r["gt_nouns_loss"]) - float(g["gt_nouns_loss"])) < 1e-4
