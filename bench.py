@@ -54,12 +54,36 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
+def host_cores():
+    """CPU cores this process may actually use: the cgroup quota / affinity mask, not the machine's core count
+    (the GPU box exposes 256 logical CPUs but grants a 1-GPU job a share of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return int(os.environ.get("SR_CPU_THREADS", min(n, 64)))
+
+
 def cpu_baseline(args):
     """The oracle's training step (fp32, CPU) on a bounded sample of the same workload."""
     from oracle.ref_encoder import SyntheticEncoder
     from oracle.ref_model import RefBackbone, RefFCGGNN, train_step
     torch.manual_seed(1238)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     enc = SyntheticEncoder()
     D = 2048 if args.backbone >= 50 else 512
@@ -94,8 +118,8 @@ def main():
     ap.add_argument("--T", type=int, default=5)
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

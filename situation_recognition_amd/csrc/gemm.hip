@@ -20,6 +20,8 @@
 //   * convolution padding and row tails read from a zero page instead of branching;
 //   * workgroup -> tile mapping is XCD-aware (each XCD walks a contiguous range of row
 //     tiles so the activation panel is reused out of its own L2).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -41,6 +43,7 @@ struct KArgs {
   const void* aux1; const void* aux2;
   float* stats;
   ConvGeom cv;
+  int debug;  // SR_GEMM_DEBUG bits (diagnostic builds of bench scripts only): 1 = skip MFMA, 2 = skip loads after the prologue
 };
 
 template <typename T> struct Frag;  // one 16-byte MFMA operand fragment
@@ -360,7 +363,362 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   gemm_body<T, TO, WAVES_M, WAVES_N, true>(p);
 }
 
-inline int tile_m_for(int N) { return N <= 64 ? 256 : 128; }
+
+// =====================================================================================================
+// v2: persistent workgroups + 3-stage LDS-DMA ring (default).
+//
+// Each workgroup walks tiles  vb, vb+G, vb+2G, ...  (vb = XCD-contiguous virtual id) and treats all the K-tiles of
+// all its output tiles as ONE stream of steps.  Step s lives in ring slot s % 3:
+//
+//     top of iteration s :  s_waitcnt vmcnt(N)   -- my DMAs of step s have landed (N = ops younger than them)
+//                           s_barrier            -- everybody's have, and everybody finished computing step s-1
+//                           issue DMAs of step s+2 into slot (s+2)%3 == (s-1)%3  (just freed)
+//                           16 ds_read_b128 + 32 MFMA from slot s%3
+//                           last K-tile of a tile: epilogue (stores), accumulators cleared
+//
+// so two steps of loads are always in flight across the barrier (counted vmcnt, never 0 in the loop;
+// cdna_hip_programming.md "Pipelining across barriers") and the next tile's first K-tiles are fetched
+// underneath the current tile's epilogue.  vmcnt also counts stores (CDNA4), so the epilogue issues a FIXED
+// number of store instructions per lane (out-of-range lanes store to a trash page) and the wait after an
+// epilogue allows for exactly those.
+// =====================================================================================================
+__device__ __attribute__((aligned(256))) unsigned char g_trash_page[64 * 16 * 2];
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <typename T, typename TO, int WAVES_M, int WAVES_N, bool CONV>
+__device__ __forceinline__ void gemm_body_v2(const KArgs& p) {
+  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64, NW = WAVES_M * WAVES_N;
+  constexpr int EPC = 16 / (int)sizeof(T), BK = 8 * EPC;
+  constexpr int A_PER_WAVE = (BM / 8) / NW, B_PER_WAVE = (BN / 8) / NW, L = A_PER_WAVE + B_PER_WAVE;
+  constexpr int STAGE = (BM + BN) * 128, NSTAGE = 3;
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide over waves");
+  static_assert(L + 32 < 64, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const int lrow = lane >> 3, csrc = (lane & 7) ^ lrow, ecol = csrc * EPC;
+
+  const int gn = (p.N + BN - 1) / BN, gm = (p.M + BM - 1) / BM;
+  const int ntiles = gm * gn, G = gridDim.x;
+  int vb = blockIdx.x;
+  {
+    const int xcd = vb & 7, q = G >> 3, r = G & 7;
+    vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+  }
+  if (vb >= ntiles) return;
+  const int my_tiles = (ntiles - vb + G - 1) / G;
+  int nkt = p.nk[0];
+  if (p.npairs > 1) nkt += p.nk[1];
+  if (p.npairs > 2) nkt += p.nk[2];
+  const int total = my_tiles * nkt;
+
+  // ---------------- loader state (for the tile whose K-tiles are being issued) ----------------
+  int ld_tile = vb, ld_kt = 0;
+  long a_row[A_PER_WAVE];
+  unsigned a_mask[A_PER_WAVE];
+  int w_row[B_PER_WAVE];
+  auto setup_rows = [&](int tile) {
+    const int tm = tile / gn, tn = tile - tm * gn;
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+      const long m = m0 + (wave + i * NW) * 8 + lrow;
+      if (!CONV) {
+        a_row[i] = m < p.M ? m : (long)p.M - 1;
+        a_mask[i] = 0xffffffffu;
+      } else if (m >= p.M) {
+        a_row[i] = 0;
+        a_mask[i] = 0;
+      } else {
+        const unsigned hw = (unsigned)(p.cv.Ho * p.cv.Wo), um = (unsigned)m;
+        const long b = um / hw;
+        const int rem = (int)(um - (unsigned)b * hw);
+        const int ho = rem / p.cv.Wo, wo = rem - ho * p.cv.Wo;
+        const int hi0 = ho * p.cv.stride - p.cv.pad, wi0 = wo * p.cv.stride - p.cv.pad;
+        a_row[i] = ((b * p.cv.H + hi0) * (long)p.cv.Wd + wi0) * p.cv.cpix;
+        const int ntap = p.kp[0].K >> p.cv.lgCseg;
+        unsigned mk = 0;
+        for (int t = 0; t < ntap; ++t) {
+          const int dh = p.cv.KW == 1 ? t : (t * 11) >> 5, dw = t - dh * p.cv.KW;
+          const int hi = hi0 + dh, wi = wi0 + dw;
+          if (hi >= 0 && hi < p.cv.H && wi >= 0 && wi < p.cv.Wd) mk |= 1u << t;
+        }
+        a_mask[i] = mk;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i) {
+      const int n = n0 + (wave + i * NW) * 8 + lrow;
+      w_row[i] = n < p.N ? n : p.N - 1;
+    }
+  };
+  setup_rows(ld_tile);
+
+  auto issue = [&](int slot) {
+    int pr = 0, kl = ld_kt;
+    if (p.npairs > 1 && kl >= p.nk[0]) { kl -= p.nk[0]; pr = 1; }
+    if (p.npairs > 2 && pr == 1 && kl >= p.nk[1]) { kl -= p.nk[1]; pr = 2; }
+    const sr_kpair& kp = p.kp[pr];
+    const int k = kl * BK + ecol;
+    char* sA = smem + slot * STAGE;
+    char* sB = sA + BM * 128;
+    long tapoff = 0;
+    int tap = 0;
+    if (CONV) {
+      tap = k >> p.cv.lgCseg;
+      const int cc = k & ((1 << p.cv.lgCseg) - 1);
+      const int dh = p.cv.KW == 1 ? tap : (tap * 11) >> 5, dw = tap - dh * p.cv.KW;
+      tapoff = ((long)dh * p.cv.Wd + dw) * p.cv.cpix + cc;
+    }
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+      const T* src;
+      if (!CONV) src = (const T*)kp.A + a_row[i] * kp.lda + k;
+      else src = ((a_mask[i] >> tap) & 1) ? (const T*)kp.A + a_row[i] + tapoff : (const T*)g_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sA + (wave + i * NW) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i) {
+      const T* src = (const T*)kp.W + (long)w_row[i] * kp.ldw + k;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sB + (wave + i * NW) * 1024), 16, 0, 0);
+    }
+    if (++ld_kt == nkt) {
+      ld_kt = 0;
+      ld_tile += G;
+      if (ld_tile < ntiles) setup_rows(ld_tile);
+    }
+  };
+
+  f32x4_t acc[4][4];
+  auto clear_acc = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+  clear_acc();
+
+  auto compute = [&](int slot) {
+    const char* sA = smem + slot * STAGE + (wm * 64 + frow) * 128;
+    const char* sB = smem + slot * STAGE + BM * 128 + (wn * 64 + frow) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int sw = ((ks * 4 + fgrp) ^ (lane & 7)) << 4;
+      Frag<T> a[4], w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const Frag<T>*>(sA + i * 16 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const Frag<T>*>(sB + j * 16 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mma<T>(w[j], a[i], acc[j][i]);
+    }
+  };
+
+  const bool two = (p.act == SR_ACT_SIGMOID_MUL || p.act == SR_ACT_TANH_BLEND);
+  const int Nv = (p.N + 3) & ~3;   // columns that may be written (pad columns up to a multiple of 4 belong to the row)
+  TO* const trash = reinterpret_cast<TO*>(g_trash_page + lane * 16);
+  const TO* const zeros = reinterpret_cast<const TO*>(g_zero_page);
+
+  // Epilogue of one finished tile: exactly 16 (32 with a second output) store instructions per lane.
+  auto epilogue = [&](int tile, int slot) {
+    const int tm = tile / gn, tn = tile - tm * gn;
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+    const bool want_stats = p.stats != nullptr;
+    float s1[4][4], s2[4][4];
+    if (want_stats) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[j][r] = s2[j][r] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fgrp * 4;
+      float bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = n + r < p.N ? n + r : p.N - 1;
+        bv[r] = (p.bias ? p.bias_scale * p.bias[nn] : 0.f) + (p.bias2 ? p.bias2[nn] : 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long m = m0 + wm * 64 + i * 16 + frow;
+        const bool ok = (m < p.M) && (n < Nv);
+        float v[4], o2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] + bv[r];
+        if (want_stats && ok) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+        }
+        if (p.res) {
+          float rv[4];
+          load4<TO>(ok ? (const TO*)p.res + m * p.ldres + n : zeros, rv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        }
+        switch (p.act) {
+          case SR_ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            break;
+          case SR_ACT_SIGMOID:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
+            break;
+          case SR_ACT_TANH:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
+            break;
+          case SR_ACT_SIGMOID_MUL: {
+            float h[4];
+            load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = sigmoidf_(v[r]); o2[r] = v[r] * h[r]; }
+          } break;
+          case SR_ACT_TANH_BLEND: {
+            float h[4], z[4];
+            load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
+            load4<TO>(ok ? (const TO*)p.aux2 + m * p.ldc + n : zeros, z);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float c = tanhf_(v[r]);
+              o2[r] = c;
+              v[r] = (1.f - z[r]) * h[r] + z[r] * c;
+            }
+          } break;
+          default: break;
+        }
+        store4<TO>(ok ? (TO*)p.C + m * p.ldc + n : trash, v);
+        if (two) store4<TO>(ok ? (TO*)p.C2 + m * p.ldc + n : trash, o2);
+      }
+    }
+    if (want_stats) {
+      float* red = reinterpret_cast<float*>(smem + slot * STAGE);  // the slot just consumed: no DMA targets it
+      lds_barrier();                                               // ... once every wave is done reading it
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = s1[j][r], b = s2[j][r];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+          if (frow == 0) {
+            const int col = wn * 64 + j * 16 + fgrp * 4 + r;
+            red[(0 * WAVES_M + wm) * BN + col] = a;
+            red[(1 * WAVES_M + wm) * BN + col] = b;
+          }
+        }
+      lds_barrier();
+      for (int t = threadIdx.x; t < 2 * BN; t += NW * 64) {
+        const int which = t / BN, col = t - which * BN;
+        if (n0 + col < p.N) {
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < WAVES_M; ++w) s += red[(which * WAVES_M + w) * BN + col];
+          p.stats[((long)tm * 2 + which) * p.N + n0 + col] = s;
+        }
+      }
+    }
+  };
+
+  // ---------------- the stream ----------------
+  int issued = 0;
+  issue(0); ++issued;
+  if (total > 1) { issue(1); ++issued; }
+  int c_tile = vb, c_kt = 0;
+  bool stored = false;
+  for (int s = 0; s < total; ++s) {
+    const int ahead = issued - s - 1;  // 0 or 1 later steps already in flight
+    if (p.debug & 2) {
+      wait_vm<0>();
+    } else if (!stored) {
+      if (ahead) wait_vm<L>(); else wait_vm<0>();
+    } else if (!two) {
+      if (ahead) wait_vm<L + 16>(); else wait_vm<16>();
+    } else {
+      if (ahead) wait_vm<L + 32>(); else wait_vm<32>();
+    }
+    stored = false;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (issued < total) {
+      if (!(p.debug & 2)) issue(issued % NSTAGE);
+      ++issued;
+    }
+    const int slot = s % NSTAGE;
+    if (!(p.debug & 1)) compute(slot);
+    if (++c_kt == nkt) {
+      epilogue(c_tile, slot);
+      stored = true;
+      c_kt = 0;
+      c_tile += G;
+      clear_acc();
+    }
+  }
+}
+
+template <typename T, typename TO, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_v2_kernel(const KArgs p) {
+  gemm_body_v2<T, TO, WAVES_M, WAVES_N, false>(p);
+}
+template <typename T, typename TO, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(const KArgs p) {
+  gemm_body_v2<T, TO, WAVES_M, WAVES_N, true>(p);
+}
+
+inline bool use_v1() {
+  static const bool v1 = [] { const char* e = getenv("SR_GEMM_V1"); return e && e[0] == '1'; }();
+  return v1;
+}
+inline int num_cus() {
+  static const int n = [] {
+    int dev = 0, cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
+    return cu > 0 ? cu : 256;
+  }();
+  return n;
+}
+
+template <typename T, typename TO, int WM, int WN>
+int launch_v2(const KArgs& k, hipStream_t st) {
+  constexpr int BM = WM * 64, BN = WN * 64;
+  const long gm = ((long)k.M + BM - 1) / BM, gn = (k.N + BN - 1) / BN;
+  if (gm * gn > 0x7fffffffL) return SR_ERR_ARG;
+  const size_t lds = 3 * (BM + BN) * 128;
+  const long ntiles = gm * gn;
+  const unsigned grid = (unsigned)(ntiles < num_cus() ? ntiles : num_cus());
+  if (k.cv.on) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v2_kernel<T, TO, WM, WN>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return SR_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv_igemm_v2_kernel<T, TO, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, st, k);
+  } else {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<T, TO, WM, WN>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return SR_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_nt_v2_kernel<T, TO, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, st, k);
+  }
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+inline int tile_m_for(int N) { return use_v1() ? (N <= 64 ? 256 : 128) : 256; }
 
 template <typename T, typename TO, int WM, int WN>
 int launch_cfg(const KArgs& k, hipStream_t st) {
@@ -385,10 +743,18 @@ int launch_cfg(const KArgs& k, hipStream_t st) {
 
 template <typename T, typename TO>
 int launch(const KArgs& k, hipStream_t st) {
-  return k.N <= 64 ? launch_cfg<T, TO, 4, 1>(k, st) : launch_cfg<T, TO, 2, 2>(k, st);
+  if (use_v1()) return k.N <= 64 ? launch_cfg<T, TO, 4, 1>(k, st) : launch_cfg<T, TO, 2, 2>(k, st);
+  return k.N <= 64 ? launch_v2<T, TO, 4, 1>(k, st) : launch_v2<T, TO, 4, 2>(k, st);
 }
 
-int dispatch(const KArgs& k, int dtype, int out_f32, hipStream_t st) {
+inline int debug_flags() {
+  static const int f = [] { const char* e = getenv("SR_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
+  return f;
+}
+
+int dispatch(const KArgs& k_in, int dtype, int out_f32, hipStream_t st) {
+  KArgs k = k_in;
+  k.debug = debug_flags();
   if (dtype == SR_F32) return launch<float, float>(k, st);
   if (dtype == SR_BF16) return out_f32 ? launch<bf16_t, float>(k, st) : launch<bf16_t, bf16_t>(k, st);
   return SR_ERR_DTYPE;
