@@ -74,7 +74,10 @@ typedef struct sr_gemm_args {
   float* stats;
 } sr_gemm_args;
 int sr_gemm(const sr_gemm_args* a, int dtype, void* stream);
-int sr_gemm_stats_tiles(int M, int N); /* rows of `stats` sr_gemm/sr_conv2d will write */
+int sr_gemm_stats_tiles(int M, int N);
+/* Diagnostic only (synchronises!): copies the in-kernel cycle stamps of the last v3 GEMM launched with
+ * SR_GEMM_DEBUG=4 to host memory: [256 blocks][8 waves][8] uint64 (0 vmcnt wait, 1 barrier, 2 DMA issue, 3 MFMA, 4 epilogue, 5 steps). */
+int sr_debug_stamps(unsigned long long* host_out, int count); /* rows of `stats` sr_gemm/sr_conv2d will write */
 
 /* NHWC convolution as implicit GEMM on the same MFMA kernel:
  * y[b,ho,wo,co] = epilogue( sum_{r,q,c} x[b, ho*s-p+r, wo*s-p+q, c] * w[co,r,q,c] + bias[co] ) (+ res)
@@ -89,8 +92,11 @@ typedef struct sr_conv_args {
   void* y;                 /* [B*Ho*Wo, Cout] */
   const float* bias;       /* folded BN shift (eval mode) or NULL */
   const void* res;         /* residual, same shape/type as y, or NULL */
-  int32_t act; int32_t _pad;
+  int32_t act; int32_t no_store; /* no_store != 0: statistics-only launch, y is not written (Cout > 128 only) */
   float* stats;            /* see sr_gemm_args.stats */
+  const float* escale;     /* optional per-output-channel multiplier: y = act(acc*escale + bias (+res)) (Cout > 128 only).
+                              With no_store it gives train-mode BatchNorm in two conv launches and no elementwise pass:
+                              launch 1 (no_store) -> statistics -> sr_bn_finalize -> launch 2 with escale=scale, bias=shift. */
 } sr_conv_args;
 int sr_conv2d(const sr_conv_args* a, int dtype, void* stream);
 

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrhip.so")
+LIB_PATH = os.environ.get("SR_LIB_PATH") or os.path.join(_HERE, "libsrhip.so")   # SR_LIB_PATH: diagnostic builds only
 
 SR_F32, SR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SIGMOID_MUL, ACT_TANH_BLEND = range(6)
@@ -38,8 +38,8 @@ class ConvArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p),
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("stem", C.c_int32),
-                ("y", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("act", C.c_int32), ("_pad", C.c_int32),
-                ("stats", C.c_void_p)]
+                ("y", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("act", C.c_int32), ("no_store", C.c_int32),
+                ("stats", C.c_void_p), ("escale", C.c_void_p)]
 
 
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
@@ -47,6 +47,7 @@ SIGNATURES = {
     "sr_abi_version": [],
     "sr_gemm": [C.POINTER(GemmArgs), _I, _P],
     "sr_gemm_stats_tiles": [_I, _I],
+    "sr_debug_stamps": [_P, _I],
     "sr_conv2d": [C.POINTER(ConvArgs), _I, _P],
     "sr_stem_prep": [_P, _P, _I, _I, _I, _I, _P],
     "sr_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P],

@@ -13,7 +13,11 @@ OUT = os.path.join(PKG, "libsrhip.so")
 OBJ = os.path.join(HERE, "_obj")
 SOURCES = ["gemm.hip", "elementwise.hip", "ggnn.hip"]
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(PKG), "include", "srhip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# -pragma-unroll-threshold: the GEMM epilogues are fully unrolled over 32 accumulator fragments; LLVM's default
+# threshold (16K) silently downgrades "#pragma unroll" to a partial unroll, which makes the accumulator index dynamic and
+# sends the accumulators to scratch memory.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
+         "-mllvm", "-pragma-unroll-threshold=400000"]
 
 
 def _hipcc():

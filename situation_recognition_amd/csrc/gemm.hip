@@ -43,6 +43,10 @@ struct KArgs {
   const void* aux1; const void* aux2;
   float* stats;
   ConvGeom cv;
+  const float* escale;    // optional per-column multiplier applied to the accumulator before the bias (v3 kernels only)
+  int no_store;           // statistics-only launch: the tile is not written (v3 kernels only)
+  const void* zero_page;  // 256 zero bytes (device address of g_zero_page, resolved once on the host)
+  void* trash_page;       // sink for out-of-range lanes' stores
   int debug;  // SR_GEMM_DEBUG bits (diagnostic builds of bench scripts only): 1 = skip MFMA, 2 = skip loads after the prologue
 };
 
@@ -384,6 +388,30 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
 // =====================================================================================================
 __device__ __attribute__((aligned(256))) unsigned char g_trash_page[64 * 16 * 2];
 
+// In-kernel cycle stamps (diagnostic runs only: SR_GEMM_DEBUG bit 2 = value 4).  [block][wave][segment] sums of
+// s_memtime deltas: 0 vmcnt wait, 1 barrier, 2 DMA issue, 3 MFMA + fragment reads, 4 epilogue, 5 steps.
+__device__ unsigned long long g_stamps[256 * 8 * 8];
+#define SR_STAMP(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
+
+// Lane id recomputed on the spot (2 VALU ops).  Used on the per-tile paths so that lane-constant values are not
+// kept live (and spilled) across the K loop: a spill reload would bring a compiler-inserted vmcnt(0) that drains
+// the LDS-DMA ring (cdna_hip_programming.md, attention pitfalls).
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+// Sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15); every lane of the row receives the total.
+// Four v_add_f32 with row_ror modifiers instead of four ds_bpermute round trips.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -484,7 +512,7 @@ __device__ __forceinline__ void gemm_body_v2(const KArgs& p) {
     for (int i = 0; i < A_PER_WAVE; ++i) {
       const T* src;
       if (!CONV) src = (const T*)kp.A + a_row[i] * kp.lda + k;
-      else src = ((a_mask[i] >> tap) & 1) ? (const T*)kp.A + a_row[i] + tapoff : (const T*)g_zero_page;
+      else src = ((a_mask[i] >> tap) & 1) ? (const T*)kp.A + a_row[i] + tapoff : (const T*)p.zero_page;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sA + (wave + i * NW) * 1024), 16, 0, 0);
     }
@@ -530,8 +558,8 @@ __device__ __forceinline__ void gemm_body_v2(const KArgs& p) {
 
   const bool two = (p.act == SR_ACT_SIGMOID_MUL || p.act == SR_ACT_TANH_BLEND);
   const int Nv = (p.N + 3) & ~3;   // columns that may be written (pad columns up to a multiple of 4 belong to the row)
-  TO* const trash = reinterpret_cast<TO*>(g_trash_page + lane * 16);
-  const TO* const zeros = reinterpret_cast<const TO*>(g_zero_page);
+  TO* const trash = reinterpret_cast<TO*>((char*)p.trash_page + lane * 16);
+  const TO* const zeros = reinterpret_cast<const TO*>(p.zero_page);
 
   // Epilogue of one finished tile: exactly 16 (32 with a second output) store instructions per lane.
   auto epilogue = [&](int tile, int slot) {
@@ -682,6 +710,434 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(c
   gemm_body_v2<T, TO, WAVES_M, WAVES_N, true>(p);
 }
 
+
+// =====================================================================================================
+// v3: 256x256 tile, 8 waves (2 x 4, each 128 x 64 = 8 x 4 MFMA fragments), for N > 128.
+//
+// Same persistent stream of K-steps as v2, but
+//   * K-step = 64-byte rows (32 bf16 / 16 f32); the ring has FOUR 32 KiB slots, so THREE steps (96 KiB) are in
+//     flight per CU; a 256x256 tile needs 1.5x fewer LDS-DMA bytes per FLOP than 256x128;
+//   * the fragments of step s+1 are read from LDS WHILE the MFMAs of step s run ("rolling" A registers: a[i] is
+//     reloaded as soon as its four MFMAs have issued; B is double-buffered), so no LDS latency is exposed at the
+//     step boundary and the top-of-step synchronisation is for the data of step s+1, one step ahead;
+//   * 12 ds_read_b128 per 32 MFMAs instead of 16.
+// 64-byte rows: 16-byte chunk c of row r is stored at chunk position c ^ ((r & 8) >> 2)  (conflict-free for the
+// ds_read_b128 lane groups, checked by enumeration); one DMA piece = 16 rows x 64 B.
+// =====================================================================================================
+// WAVES_N = 4: 256x256 tile, 8 waves, 4-slot ring (128 KiB), one workgroup per CU   -- compute-heavy shapes
+// WAVES_N = 2: 256x128 tile, 4 waves, 3-slot ring ( 72 KiB), TWO workgroups per CU  -- output-heavy shapes (small K, wide N):
+//              one workgroup's epilogue (stores) overlaps the other's K loop instead of idling the matrix cores.
+template <typename T, typename TO, bool CONV, int WAVES_N>
+__device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
+  constexpr int BM = 256, BN = 64 * WAVES_N, WAVES_M = 2, NW = WAVES_M * WAVES_N;
+  constexpr int EPC = 16 / (int)sizeof(T), BK = 4 * EPC;
+  constexpr int NSLOT = WAVES_N == 4 ? 4 : 3;
+  constexpr int SLOT = (BM + BN) * 64, STG_OFF = NSLOT * SLOT;
+  constexpr int A_PER = (BM / 16) / NW, B_PER = (BN / 16) / NW;
+  constexpr int L = A_PER + B_PER;                      // DMA instructions per lane per step
+  constexpr bool STAGED = sizeof(TO) == 2;              // 16-bit outputs leave through a per-wave LDS staging strip
+  constexpr int S = STAGED ? 16 : 32;                   // store instructions per lane per epilogue (single output)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int ecol = ((lane & 3) ^ ((lane >> 5) << 1)) * EPC;       // source chunk (swizzled) -> element offset
+  const int fsw = ((lane >> 4) ^ ((lane & 8) >> 2)) << 4;         // fragment read: byte offset inside the 64-B row
+
+  const int gn = (p.N + BN - 1) / BN, gm = (p.M + BM - 1) / BM;
+  const int ntiles = gm * gn, G = gridDim.x;
+  int vb = blockIdx.x;
+  {
+    const int xcd = vb & 7, q = G >> 3, r = G & 7;
+    vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+  }
+  if (vb >= ntiles) return;
+  const int my_tiles = (ntiles - vb + G - 1) / G;
+  int nkt = p.nk[0];
+  if (p.npairs > 1) nkt += p.nk[1];
+  if (p.npairs > 2) nkt += p.nk[2];
+  const int total = my_tiles * nkt;
+
+  // ---------------- loader: per-lane base pointers, rebuilt only when the tile or the operand pair changes ----------------
+  int ld_tile = vb, ld_kt = 0, ld_pr = 0, ld_k0 = 0;   // ld_k0: first K-step of the current pair
+  const T* a_ptr[A_PER];
+  const T* w_ptr[B_PER];
+  unsigned a_mask[A_PER];
+  auto setup_ptrs = [&](int tile, int pr) {
+    const int tm = tile / gn, tn = tile - tm * gn;
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+    const int fl = fresh_lane();
+    const int prow = fl >> 2;
+    const int ec = ((fl & 3) ^ ((fl >> 5) << 1)) * EPC;
+    // field-wise selects: indexing the by-value argument struct with a run-time index makes hipcc copy it to scratch
+    sr_kpair kp;
+    kp.A = pr == 0 ? p.kp[0].A : (pr == 1 ? p.kp[1].A : p.kp[2].A);
+    kp.W = pr == 0 ? p.kp[0].W : (pr == 1 ? p.kp[1].W : p.kp[2].W);
+    kp.lda = pr == 0 ? p.kp[0].lda : (pr == 1 ? p.kp[1].lda : p.kp[2].lda);
+    kp.ldw = pr == 0 ? p.kp[0].ldw : (pr == 1 ? p.kp[1].ldw : p.kp[2].ldw);
+    kp.K = pr == 0 ? p.kp[0].K : (pr == 1 ? p.kp[1].K : p.kp[2].K);
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const long m = m0 + (wave + i * NW) * 16 + prow;
+      if (!CONV) {
+        a_ptr[i] = (const T*)kp.A + (m < p.M ? m : (long)p.M - 1) * kp.lda + ec;
+        a_mask[i] = 0xffffffffu;
+      } else if (m >= p.M) {
+        a_ptr[i] = (const T*)kp.A;
+        a_mask[i] = 0;
+      } else {
+        const unsigned hw = (unsigned)(p.cv.Ho * p.cv.Wo), um = (unsigned)m;
+        const long b = um / hw;
+        const int rem = (int)(um - (unsigned)b * hw);
+        const int ho = rem / p.cv.Wo, wo = rem - ho * p.cv.Wo;
+        const int hi0 = ho * p.cv.stride - p.cv.pad, wi0 = wo * p.cv.stride - p.cv.pad;
+        a_ptr[i] = (const T*)kp.A + ((b * p.cv.H + hi0) * (long)p.cv.Wd + wi0) * p.cv.cpix + ec;
+        const int ntap = kp.K >> p.cv.lgCseg;
+        unsigned mk = 0;
+        for (int t = 0; t < ntap; ++t) {
+          const int dh = p.cv.KW == 1 ? t : (t * 11) >> 5, dw = t - dh * p.cv.KW;
+          const int hi = hi0 + dh, wi = wi0 + dw;
+          if (hi >= 0 && hi < p.cv.H && wi >= 0 && wi < p.cv.Wd) mk |= 1u << t;
+        }
+        a_mask[i] = mk;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int n = n0 + (wave + i * NW) * 16 + prow;
+      w_ptr[i] = (const T*)kp.W + (long)(n < p.N ? n : p.N - 1) * kp.ldw + ec;
+    }
+  };
+  setup_ptrs(ld_tile, 0);
+
+  // scalar (wave-uniform) description of the step being issued; computed once per step
+  long st_aoff = 0, st_woff = 0;
+  int st_tap = 0, st_slot = 0;
+  auto begin_issue = [&](int slot) {
+    const int kl = ld_kt - ld_k0;               // K-step inside the current pair
+    const int k = kl * BK;
+    st_slot = slot;
+    st_woff = k;
+    if (CONV) {
+      st_tap = k >> p.cv.lgCseg;               // uniform: BK <= Cseg
+      const int cc = k & ((1 << p.cv.lgCseg) - 1);
+      const int dh = p.cv.KW == 1 ? st_tap : (st_tap * 11) >> 5, dw = st_tap - dh * p.cv.KW;
+      st_aoff = ((long)dh * p.cv.Wd + dw) * p.cv.cpix + cc;
+    } else {
+      st_aoff = k;
+    }
+  };
+  auto issue_piece = [&](int q) {              // q < A_PER: A pieces; then B pieces
+    char* dst = smem + st_slot * SLOT + (q >= A_PER ? BM * 64 + (wave + (q - A_PER) * NW) * 1024 : (wave + q * NW) * 1024);
+    const T* src;
+    if (q < A_PER) {
+      src = a_ptr[q < A_PER ? q : 0] + st_aoff;
+      if (CONV) src = ((a_mask[q < A_PER ? q : 0] >> st_tap) & 1) ? src : (const T*)p.zero_page;
+    } else {
+      src = w_ptr[q >= A_PER ? q - A_PER : 0] + st_woff;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto end_issue = [&]() {
+    if (++ld_kt == nkt) {
+      ld_kt = 0; ld_pr = 0; ld_k0 = 0;
+      ld_tile += G;
+      if (ld_tile < ntiles) setup_ptrs(ld_tile, 0);
+    } else if (ld_pr + 1 < p.npairs && ld_kt - ld_k0 == (ld_pr == 0 ? p.nk[0] : p.nk[1])) {
+      ld_k0 = ld_kt;
+      ++ld_pr;
+      setup_ptrs(ld_tile, ld_pr);
+    }
+  };
+
+  f32x4_t acc[4][8];  // [n-fragment j][m-fragment i]
+  auto clear_acc = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+  clear_acc();
+
+  const int a_off = (wm * 128 + (lane & 15)) * 64 + fsw;
+  const int b_off = BM * 64 + (wn * 64 + (lane & 15)) * 64 + fsw;
+  auto rdA = [&](int slot, int i) { return *reinterpret_cast<const Frag<T>*>(smem + slot * SLOT + a_off + i * 16 * 64); };
+  auto rdB = [&](int slot, int j) { return *reinterpret_cast<const Frag<T>*>(smem + slot * SLOT + b_off + j * 16 * 64); };
+
+  const bool two = (p.act == SR_ACT_SIGMOID_MUL || p.act == SR_ACT_TANH_BLEND);
+  const int Nv = (p.N + 3) & ~3;
+  const TO* const zeros = reinterpret_cast<const TO*>(p.zero_page);
+
+  auto epilogue = [&](int tile) {
+    const int tm = tile / gn, tn = tile - tm * gn;
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+    const bool want_stats = p.stats != nullptr;
+    const int el = fresh_lane();
+    const int frow = el & 15, fgrp = el >> 4;
+    TO* const trash = reinterpret_cast<TO*>((char*)p.trash_page + el * 16);
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + j * 16 + fgrp * 4 + r;
+        const int nn = n < p.N ? n : p.N - 1;
+        bv[j][r] = (p.bias ? p.bias_scale * p.bias[nn] : 0.f) + (p.bias2 ? p.bias2[nn] : 0.f);
+      }
+    const bool scaled = p.escale != nullptr;
+    if (scaled) {  // fold the multiplier into the accumulators once (registers: none extra)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wn * 64 + j * 16 + fgrp * 4 + r;
+          const float e = p.escale[n < p.N ? n : p.N - 1];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[j][i][r] *= e;
+        }
+    }
+    if (want_stats) {
+      // pass 1 (column-major over the fragments, 8 live sums): per-channel sum / sum of squares of acc + bias over this
+      // wave's 128 rows -> its own partial row [2*tm + wm] of `stats` (no LDS, no barrier: the two wave groups run
+      // half a step apart and must not meet at a barrier here)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        const int nj = n0 + wn * 64 + j * 16 + fgrp * 4;
+        const bool nok = nj < Nv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool ok = nok && (m0 + wm * 128 + i * 16 + frow < p.M);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = ok ? acc[j][i][r] + bv[j][r] : 0.f;
+            s1[r] += v;
+            s2[r] += v * v;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+        if (frow == 0) {
+          float* row = p.stats + ((long)(tm * WAVES_M + wm) * 2) * p.N;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nj + r < p.N) { row[nj + r] = s1[r]; row[p.N + nj + r] = s2[r]; }
+        }
+      }
+    }
+    // pass 2, i-major: one 16-row x 64-column strip of the wave's tile at a time
+    if (!p.no_store) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long m = m0 + wm * 128 + i * 16 + frow;
+      char* stg = smem + STG_OFF + wave * 2048;             // per-wave [16 rows][64 cols] 16-bit strip; 16-B chunk c of row r at c ^ (r & 7)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + fgrp * 4;
+        const bool ok = (m < p.M) && (n < Nv);
+        float v[4], o2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] + bv[j][r];
+        if (p.res) {
+          float rv[4];
+          load4<TO>(ok ? (const TO*)p.res + m * p.ldres + n : zeros, rv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        }
+        switch (p.act) {
+          case SR_ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            break;
+          case SR_ACT_SIGMOID:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
+            break;
+          case SR_ACT_TANH:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
+            break;
+          case SR_ACT_SIGMOID_MUL: {
+            float h[4];
+            load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = sigmoidf_(v[r]); o2[r] = v[r] * h[r]; }
+          } break;
+          case SR_ACT_TANH_BLEND: {
+            float h[4], z[4];
+            load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
+            load4<TO>(ok ? (const TO*)p.aux2 + m * p.ldc + n : zeros, z);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float c = tanhf_(v[r]);
+              o2[r] = c;
+              v[r] = (1.f - z[r]) * h[r] + z[r] * c;
+            }
+          } break;
+          default: break;
+        }
+        if (STAGED && !two) {
+          store4<TO>(reinterpret_cast<TO*>(stg + frow * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8), v);
+        } else {
+          store4<TO>(ok ? (TO*)p.C + m * p.ldc + n : trash, v);
+          if (two) store4<TO>(ok ? (TO*)p.C2 + m * p.ldc + n : trash, o2);
+        }
+      }
+      if (STAGED && !two) {
+        // the strip is wave-private: drain my LDS writes, then every lane moves 16 contiguous bytes (8 lanes = one
+        // 128-byte row segment) -> 2 store instructions per strip, full-line coalescing
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r16 = h * 8 + (el >> 3), c8 = (el & 7) * 8;
+          const long mm = m0 + wm * 128 + i * 16 + r16;
+          const int nn = n0 + wn * 64 + c8;
+          const uint4 val = *reinterpret_cast<const uint4*>(stg + r16 * 128 + (((el & 7) ^ (r16 & 7)) << 4));
+          const bool okk = (mm < p.M) && (nn + 8 <= Nv);
+          if (okk || nn >= Nv || mm >= p.M) {
+            *reinterpret_cast<uint4*>(okk ? (char*)((TO*)p.C + mm * p.ldc + nn) : (char*)p.trash_page + el * 16) = val;
+          } else {  // ragged right edge (N not a multiple of 8): element-wise, still one "store slot"
+            const unsigned wv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (nn + e < Nv)
+                reinterpret_cast<unsigned short*>(p.C)[mm * p.ldc + nn + e] = (unsigned short)(wv[e >> 1] >> ((e & 1) * 16));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // strip reads done before the next strip overwrites it
+      }
+    }
+    }
+  };
+
+  // ---------------- phase offset between workgroups ----------------
+  // All workgroups run tiles of equal length, so left alone they compute in lockstep and then ALL store their tiles
+  // at once: HBM idles during the K loops and is oversubscribed during the epilogues (measured: store phase as long
+  // as the K loop on output-heavy shapes).  Starting workgroup g with a delay of (g mod 8)/8 of a tile period keeps
+  // only 1/8 of the chip in its store phase at any time.  Purely a timing nudge: no correctness dependence.
+  if (WAVES_N == 2 && my_tiles >= 4 && !(p.debug & 8)) {
+    // two workgroups share a CU (second dispatch round = upper half of the grid): offset them by half a tile period so
+    // that one is in its K loop while the other drains its stores
+    const unsigned long long period = (unsigned long long)nkt * 2300ull + 16000ull;   // cycles per tile, roughly
+    // which of the two am I?  The workgroup whose LDS allocation does not start at 0 (HW_REG_LDS_ALLOC.LDS_BASE) is the second
+    // one on its CU -- independent of how the dispatcher numbered us.
+    const unsigned lds_base = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (11 << 11));
+    const unsigned long long delay = lds_base != 0 ? period / 2 : 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t_start < delay) __builtin_amdgcn_s_sleep(32);
+  }
+
+  // ---------------- prologue: up to 4 steps in flight, fragments of step 0 into registers ----------------
+  int issued = 0;
+  for (; issued < NSLOT && issued < total; ++issued) {
+    begin_issue(issued);
+#pragma unroll
+    for (int q = 0; q < L; ++q) issue_piece(q);
+    end_issue();
+  }
+  if (issued >= 4) wait_vm<3 * L>(); else if (issued == 3) wait_vm<2 * L>(); else if (issued == 2) wait_vm<L>(); else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  Frag<T> a[8], b[4], bs[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = rdA(0, i);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = rdB(0, j);
+  bs[0] = b[2]; bs[1] = b[3];
+
+  int c_tile = vb, c_kt = 0;
+  bool stored = false;
+  #ifdef SR_STAMPS
+  const bool stamp = (p.debug & 4) != 0;
+#else
+  constexpr bool stamp = false;
+#endif
+  unsigned long long tw = 0, tb = 0, tm_ = 0, te = 0, t0 = 0, t1 = 0;
+
+  // wait until my DMA pieces of step k have landed: ops younger than them = later groups (+ the stores of an epilogue
+  // issued since; counted once -- afterwards the plain count is merely stricter)
+  auto wait_step = [&](int k) {
+    if (k >= total) return;
+    const int later = issued - k - 1;  // 0..2
+    if (stored && !two) {
+      if (later >= 2) wait_vm<2 * L + S>(); else if (later == 1) wait_vm<L + S>(); else wait_vm<S>();
+    } else {
+      if (later >= 2) wait_vm<2 * L>(); else if (later == 1) wait_vm<L>(); else wait_vm<0>();
+    }
+    stored = false;
+  };
+  // (A variant that ran waves 4-7 half a step behind waves 0-3, two barriers per step, was measured 1.4x SLOWER:
+  //  every extra barrier drains the rolling LDS reads.  One barrier per 32 MFMAs it is.)
+  for (int s = 0; s < total; ++s) {
+    const bool has_next = s + 1 < total;
+    const bool tile_end = (c_kt + 1 == nkt);
+    const bool roll = has_next && !tile_end;  // across a tile end the fragments are fetched after the epilogue (registers)
+    const int nslot = (s + 1) % NSLOT;
+    bool do_issue = false;
+    if (stamp) SR_STAMP(t0);
+    if (has_next) {
+      wait_step(s + 1);              // my pieces of step s+1 have landed
+      if (stamp) { SR_STAMP(t1); tw += t1 - t0; }
+      lds_barrier();                 // everybody's have; my reads of slot s%4 are complete (lgkmcnt 0) -> it may be refilled
+      if (stamp) { SR_STAMP(t0); tb += t0 - t1; }
+      if (issued < total) { do_issue = true; begin_issue(issued % NSLOT); }
+    }
+    // 32 MFMAs in two sweeps over the 8 row fragments: sweep 0 uses b[0], b[1], sweep 1 uses b[2], b[3].  In sweep 1 every
+    // a[i] dies after its two MFMAs and is reloaded for step s+1 on the spot; b[0], b[1] (dead after sweep 0) are reloaded in
+    // sweep 1 as well; only b[2], b[3] of the next step need spare registers (bs).  The 4 DMA instructions of step s+4
+    // are issued in sweep 0.
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      mma<T>(b[0], a[i], acc[0][i]);
+      mma<T>(b[1], a[i], acc[1][i]);
+      if (i < L && do_issue) issue_piece(i);
+      if (roll && i == 4) bs[0] = rdB(nslot, 2);
+      if (roll && i == 6) bs[1] = rdB(nslot, 3);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      mma<T>(b[2], a[i], acc[2][i]);
+      mma<T>(b[3], a[i], acc[3][i]);
+      if (roll) {
+        a[i] = rdA(nslot, i);
+        if (i == 0) b[0] = rdB(nslot, 0);
+        if (i == 1) b[1] = rdB(nslot, 1);
+      }
+    }
+    if (do_issue) { end_issue(); ++issued; }
+    if (roll) { b[2] = bs[0]; b[3] = bs[1]; }
+    ++c_kt;
+    if (stamp) { SR_STAMP(t1); tm_ += t1 - t0; t0 = t1; }
+    if (tile_end) {
+      epilogue(c_tile);
+      stored = !p.no_store;
+      c_kt = 0;
+      c_tile += G;
+      clear_acc();
+      if (has_next) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = rdA(nslot, i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = rdB(nslot, j);
+      }
+      if (stamp) { SR_STAMP(t1); te += t1 - t0; }
+    }
+  }
+  if (stamp && blockIdx.x < 256 && (threadIdx.x & 63) == 0) {
+    unsigned long long* o = g_stamps + (blockIdx.x * 8 + wave) * 8;
+    o[0] = tw; o[1] = tb; o[2] = 0; o[3] = tm_; o[4] = te; o[5] = (unsigned long long)total;
+  }
+}
+
+template <typename T, typename TO, int WAVES_N>
+__global__ __launch_bounds__(128 * WAVES_N, 2) void gemm_nt_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, false, WAVES_N>(p); }
+template <typename T, typename TO, int WAVES_N>
+__global__ __launch_bounds__(128 * WAVES_N, 2) void conv_igemm_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, true, WAVES_N>(p); }
+
 inline bool use_v1() {
   static const bool v1 = [] { const char* e = getenv("SR_GEMM_V1"); return e && e[0] == '1'; }();
   return v1;
@@ -718,6 +1174,42 @@ int launch_v2(const KArgs& k, hipStream_t st) {
   return SR_OK;
 }
 
+inline bool use_v3() {
+  static const bool off = [] { const char* e = getenv("SR_GEMM_NO_V3"); return e && e[0] == '1'; }();
+  return !off && !use_v1();
+}
+
+template <typename T, typename TO, int WN>
+int launch_v3(const KArgs& k_in, hipStream_t st) {
+  KArgs k = k_in;
+  for (int i = 0; i < 3; ++i) k.nk[i] *= 2;  // host counts 128-byte K-tiles; v3 steps are 64 bytes
+  constexpr int BN = 64 * WN, NSLOT = WN == 4 ? 4 : 3, NTHR = 128 * WN, WG_PER_CU = WN == 4 ? 1 : 2;
+  const long gm = ((long)k.M + 255) / 256, gn = (k.N + BN - 1) / BN;
+  if (gm * gn > 0x7fffffffL) return SR_ERR_ARG;
+  const size_t lds = NSLOT * (256 + BN) * 64 + 2 * WN * 2048;
+  const long ntiles = gm * gn, cap = (long)num_cus() * WG_PER_CU;
+  const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+  if (k.cv.on) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v3_kernel<T, TO, WN>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return SR_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN>), dim3(grid), dim3(NTHR), lds, st, k);
+  } else {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v3_kernel<T, TO, WN>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return SR_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_nt_v3_kernel<T, TO, WN>), dim3(grid), dim3(NTHR), lds, st, k);
+  }
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+// 256x128 / two workgroups per CU when the tile's K loop is short relative to its epilogue (output-heavy)
+inline bool prefer_narrow(const KArgs& k) {
+  static const int force = [] { const char* e = getenv("SR_GEMM_NARROW"); return e ? atoi(e) : -1; }();
+  return force > 0;   // measured: no gain over the 256x256 tile on output-heavy shapes; kept for N <= 128 and experiments
+}
+
 inline int tile_m_for(int N) { return use_v1() ? (N <= 64 ? 256 : 128) : 256; }
 
 template <typename T, typename TO, int WM, int WN>
@@ -744,6 +1236,7 @@ int launch_cfg(const KArgs& k, hipStream_t st) {
 template <typename T, typename TO>
 int launch(const KArgs& k, hipStream_t st) {
   if (use_v1()) return k.N <= 64 ? launch_cfg<T, TO, 4, 1>(k, st) : launch_cfg<T, TO, 2, 2>(k, st);
+  if (k.N > 64 && use_v3()) return (k.N <= 128 || prefer_narrow(k)) ? launch_v3<T, TO, 2>(k, st) : launch_v3<T, TO, 4>(k, st);
   return k.N <= 64 ? launch_v2<T, TO, 4, 1>(k, st) : launch_v2<T, TO, 4, 2>(k, st);
 }
 
@@ -752,9 +1245,23 @@ inline int debug_flags() {
   return f;
 }
 
+struct Pages { void* zero; void* trash; };
+inline const Pages& pages() {
+  static const Pages pg = [] {
+    Pages q{nullptr, nullptr};
+    if (hipGetSymbolAddress(&q.zero, HIP_SYMBOL(g_zero_page)) != hipSuccess) q.zero = nullptr;
+    if (hipGetSymbolAddress(&q.trash, HIP_SYMBOL(g_trash_page)) != hipSuccess) q.trash = nullptr;
+    return q;
+  }();
+  return pg;
+}
+
 int dispatch(const KArgs& k_in, int dtype, int out_f32, hipStream_t st) {
   KArgs k = k_in;
   k.debug = debug_flags();
+  k.zero_page = pages().zero;
+  k.trash_page = pages().trash;
+  if (!k.zero_page || !k.trash_page) return SR_ERR_LAUNCH;
   if (dtype == SR_F32) return launch<float, float>(k, st);
   if (dtype == SR_BF16) return out_f32 ? launch<bf16_t, float>(k, st) : launch<bf16_t, bf16_t>(k, st);
   return SR_ERR_DTYPE;
@@ -764,7 +1271,15 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+extern "C" int sr_debug_stamps(unsigned long long* host_out, int count) {
+  if (!host_out || count <= 0 || count > 256 * 8 * 8) return SR_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return SR_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * count) != hipSuccess) return SR_ERR_LAUNCH;
+  return SR_OK;
+}
+
 extern "C" int sr_gemm_stats_tiles(int M, int N) {
+  if (!use_v1() && N > 64 && use_v3()) return 2 * ((M + 255) / 256);  // v3: one partial row per 128-row wave group
   const int bm = tile_m_for(N);
   return (M + bm - 1) / bm;
 }
@@ -832,5 +1347,8 @@ extern "C" int sr_conv2d(const sr_conv_args* a, int dtype, void* stream) {
   k.npairs = 1; k.M = (int)M; k.N = a->Cout; k.act = a->act;
   k.C = a->y; k.ldc = a->Cout; k.bias = a->bias; k.bias_scale = 1.f;
   k.res = a->res; k.ldres = a->Cout; k.stats = a->stats;
+  k.escale = a->escale; k.no_store = a->no_store;
+  if ((a->escale || a->no_store) && !(a->Cout > 64 && use_v3())) return SR_ERR_UNSUPPORTED;
+  if (a->no_store && !a->stats) return SR_ERR_ARG;
   return dispatch(k, dtype, 0, (hipStream_t)stream);
 }

@@ -187,6 +187,8 @@ class resnet(nn.Module):
         self.dtype = dtype
         self.depth = depth
         self._units = None
+        self.two_pass = False          # train-mode BN of output-heavy 1x1 convs in two conv launches (see _unit); measured slower
+                                       # than conv + bn_apply with the current epilogue (1280 vs 1138 ms/step), kept selectable
         self._stats_epoch = 0          # bumped whenever a train-mode pass changed running statistics
         self._pending_tracked = 0      # num_batches_tracked increments not yet written to the buffers
         self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_counters())
@@ -223,8 +225,19 @@ class resnet(nn.Module):
             y = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=b, res=res, relu=relu, stem_hw=stem_hw)
             return ops.maxpool3x3s2(y) if pool_after else y
         w, gamma, beta = u.raw(dt)
-        y, st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, want_stats=True, stem_hw=stem_hw)
         rm, rv, padded = u.running()
+        if self.two_pass and u.k == 1 and u.cout_p >= 2 * u.cin_p and u.cout_p > 128 and not pool_after:
+            # Output-heavy 1x1 conv (bottleneck expansion / downsample): launch it twice instead of conv -> raw tensor ->
+            # elementwise pass.  Launch 1 only produces the batch statistics (nothing is written); launch 2 recomputes the
+            # cheap GEMM and applies scale/shift (+identity, ReLU) in its epilogue.  HBM traffic per output element drops
+            # from 5 accesses (write raw, read raw, read identity, write) to 2 (read identity, write).
+            st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, stats_only=True)
+            Ho, Wo = (x.shape[1] - 1) // u.stride + 1, (x.shape[2] - 1) // u.stride + 1
+            scale, shift = ops.bn_finalize(st, x.shape[0] * Ho * Wo, gamma, beta, rm, rv, momentum, u.bn.eps)
+            if padded:
+                u.writeback(rm, rv)
+            return ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=shift, escale=scale, res=res, relu=relu)
+        y, st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, want_stats=True, stem_hw=stem_hw)
         scale, shift = ops.bn_finalize(st, y.numel() // u.cout_p, gamma, beta, rm, rv, momentum, u.bn.eps)
         if padded:
             u.writeback(rm, rv)

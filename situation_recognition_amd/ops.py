@@ -78,7 +78,8 @@ def stats_tiles(M, N):
     return lib().sr_gemm_stats_tiles(int(M), int(N))
 
 
-def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_stats=False, stem_hw=None):
+def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_stats=False, stem_hw=None, escale=None,
+           stats_only=False, out=None):
     """x: NHWC [B,H,W,Cin] (or, with stem_hw=(H,W), the padded NHWC4 image from stem_prep);
     w: packed [Cout, KH*KW*Cin] (stem: [Cout, 256]).  Returns y [B,Ho,Wo,Cout] (and stats partials)."""
     require_gpu(x, w, bias, res)
@@ -90,17 +91,24 @@ def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_st
     else:
         H, W_, Cin = x.shape[1], x.shape[2], x.shape[3]
         Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W_ + 2 * pad - KH) // stride + 1
-    y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
+    if stats_only:
+        want_stats, y = True, None
+    else:
+        y = out if out is not None else torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
     stats = None
     if want_stats:
         stats = torch.empty((stats_tiles(B * Ho * Wo, Cout), 2, Cout), device=x.device, dtype=torch.float32)
     a.x, a.w, a.B, a.H, a.W, a.Cin, a.Cout = x.data_ptr(), w.data_ptr(), B, H, W_, Cin, Cout
     a.KH, a.KW, a.stride, a.pad, a.stem = KH, KH, stride, pad, int(stem_hw is not None)
-    a.y, a.bias, a.res, a.act, a.stats = y.data_ptr(), ptr(_f32(bias, "bias")), ptr(res), (ACT_RELU if relu else ACT_NONE), ptr(stats)
-    if res is not None and (res.shape != y.shape or res.dtype != y.dtype):
+    a.y = x.data_ptr() if stats_only else y.data_ptr()          # never written when stats_only
+    a.bias, a.res, a.act, a.stats = ptr(_f32(bias, "bias")), ptr(res), (ACT_RELU if relu else ACT_NONE), ptr(stats)
+    a.escale, a.no_store = ptr(_f32(escale, "escale")), int(stats_only)
+    if res is not None and (tuple(res.shape) != (B, Ho, Wo, Cout) or res.dtype != x.dtype):
         raise L.SrError("conv2d: residual shape/dtype mismatch")
     flops = 2.0 * B * Ho * Wo * Cout * KH * KH * Cin
     check(_timed("conv", flops, 0, lambda: lib().sr_conv2d(C.byref(a), dtype_code(x.dtype), stream())), "sr_conv2d")
+    if stats_only:
+        return stats
     return (y, stats) if want_stats else y
 
 

@@ -155,6 +155,29 @@ def test_batchnorm_train_two_phase(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_batchnorm_train_two_launch_conv(ops, dtype):
+    """Output-heavy 1x1 conv: statistics-only launch, finalize, then the conv again with scale/shift (+identity, ReLU)
+    in its epilogue -- no raw tensor, no elementwise pass."""
+    B, H, W, Cin, Cout = 3, 10, 9, 64, 256
+    x = rnd(B, Cin, H, W, dtype=dtype, seed=1)
+    w = rnd(Cout, Cin, 1, 1, dtype=dtype, seed=2, scale=0.2)
+    idn = rnd(B, H, W, Cout, dtype=dtype, seed=5)
+    gamma, beta = 0.5 + torch.rand(Cout), rnd(Cout, seed=3, scale=0.2)
+    rm, rv = rnd(Cout, seed=4, scale=0.1), 0.5 + torch.rand(Cout)
+    conv = F.conv2d(x.float(), w.float())
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.relu(F.batch_norm(conv, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+                 + idn.float().permute(0, 3, 1, 2))
+    xh, wp = x.permute(0, 2, 3, 1).contiguous().cuda(), pack_w(w).cuda()
+    st = ops.conv2d(xh, wp, Cout, 1, 1, 0, stats_only=True)
+    rm_d, rv_d = rm.cuda(), rv.cuda()
+    scale, shift = ops.bn_finalize(st, B * H * W, gamma.cuda(), beta.cuda(), rm_d, rv_d, 0.1, 1e-5)
+    y = ops.conv2d(xh, wp, Cout, 1, 1, 0, bias=shift, escale=scale, res=idn.cuda(), relu=True)
+    close(y.permute(0, 3, 1, 2), ref, dtype, k=2.0)
+    assert (rm_d.cpu() - rm_ref).abs().max() < 2e-3 and (rv_d.cpu() - rv_ref).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_pools(ops, dtype):
     x = rnd(3, 64, 13, 17, dtype=dtype, seed=1)
     xh = x.permute(0, 2, 3, 1).contiguous().cuda()

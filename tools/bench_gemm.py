@@ -43,12 +43,16 @@ conv_case("l1 1x1 256->64", 56, 256, 64, 1, 1)
 conv_case("l2 3x3 128->128", 28, 128, 128, 3, 1)
 conv_case("l2 1x1 128->512", 28, 128, 512, 1, 1)
 conv_case("l2 1x1 512->128", 28, 512, 128, 1, 1)
+BB = B
+B = int(os.environ.get("B3", "6144"))
 conv_case("l3 1x1 1024->256", 14, 1024, 256, 1, 1)
 conv_case("l3 3x3 256->256", 14, 256, 256, 3, 1)
 conv_case("l3 1x1 256->1024", 14, 256, 1024, 1, 1)
 conv_case("l4 3x3 512->512", 7, 512, 512, 3, 1)
 conv_case("l4 1x1 512->2048", 7, 512, 2048, 1, 1)
 gemm_case("ggnn n (M=B*6)", B * 6, 2048, 2048)
+gemm_case("ggnn dW (K=M)", 2048, 2048, B * 6)
+gemm_case("classifier", B * 6, 2001, 2048)
 gemm_case("ggnn z 2-pair", B * 6, 2048, 2048, 2)
 gemm_case("square 4096", 4096, 4096, 4096)
 gemm_case("square 8192", 8192, 8192, 8192)
