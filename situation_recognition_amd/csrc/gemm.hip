@@ -419,7 +419,7 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <typename T, typename TO, int WAVES_M, int WAVES_N, bool CONV>
+template <typename T, typename TO, int WAVES_M, int WAVES_N, bool CONV, int EPI>
 __device__ __forceinline__ void gemm_body_v2(const KArgs& p) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64, NW = WAVES_M * WAVES_N;
   constexpr int EPC = 16 / (int)sizeof(T), BK = 8 * EPC;
@@ -556,7 +556,8 @@ __device__ __forceinline__ void gemm_body_v2(const KArgs& p) {
     }
   };
 
-  const bool two = (p.act == SR_ACT_SIGMOID_MUL || p.act == SR_ACT_TANH_BLEND);
+  constexpr bool two = (EPI == SR_ACT_SIGMOID_MUL || EPI == SR_ACT_TANH_BLEND);
+  const bool relu = (p.act == SR_ACT_RELU);
   const int Nv = (p.N + 3) & ~3;   // columns that may be written (pad columns up to a multiple of 4 belong to the row)
   TO* const trash = reinterpret_cast<TO*>((char*)p.trash_page + lane * 16);
   const TO* const zeros = reinterpret_cast<const TO*>(p.zero_page);
@@ -600,37 +601,32 @@ __device__ __forceinline__ void gemm_body_v2(const KArgs& p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += rv[r];
         }
-        switch (p.act) {
-          case SR_ACT_RELU:
+        if constexpr (EPI == 0) {
+          if (relu) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            break;
-          case SR_ACT_SIGMOID:
+          }
+        } else if constexpr (EPI == SR_ACT_SIGMOID) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
-            break;
-          case SR_ACT_TANH:
+          for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
+        } else if constexpr (EPI == SR_ACT_TANH) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
-            break;
-          case SR_ACT_SIGMOID_MUL: {
-            float h[4];
-            load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
+          for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
+        } else if constexpr (EPI == SR_ACT_SIGMOID_MUL) {
+          float h[4];
+          load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = sigmoidf_(v[r]); o2[r] = v[r] * h[r]; }
-          } break;
-          case SR_ACT_TANH_BLEND: {
-            float h[4], z[4];
-            load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
-            load4<TO>(ok ? (const TO*)p.aux2 + m * p.ldc + n : zeros, z);
+          for (int r = 0; r < 4; ++r) { v[r] = sigmoidf_(v[r]); o2[r] = v[r] * h[r]; }
+        } else if constexpr (EPI == SR_ACT_TANH_BLEND) {
+          float h[4], z[4];
+          load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
+          load4<TO>(ok ? (const TO*)p.aux2 + m * p.ldc + n : zeros, z);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float c = tanhf_(v[r]);
-              o2[r] = c;
-              v[r] = (1.f - z[r]) * h[r] + z[r] * c;
-            }
-          } break;
-          default: break;
+          for (int r = 0; r < 4; ++r) {
+            const float c = tanhf_(v[r]);
+            o2[r] = c;
+            v[r] = (1.f - z[r]) * h[r] + z[r] * c;
+          }
         }
         store4<TO>(ok ? (TO*)p.C + m * p.ldc + n : trash, v);
         if (two) store4<TO>(ok ? (TO*)p.C2 + m * p.ldc + n : trash, o2);
@@ -644,8 +640,7 @@ __device__ __forceinline__ void gemm_body_v2(const KArgs& p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float a = s1[j][r], b = s2[j][r];
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+          a = row16_sum(a); b = row16_sum(b);
           if (frow == 0) {
             const int col = wn * 64 + j * 16 + fgrp * 4 + r;
             red[(0 * WAVES_M + wm) * BN + col] = a;
@@ -701,15 +696,14 @@ __device__ __forceinline__ void gemm_body_v2(const KArgs& p) {
   }
 }
 
-template <typename T, typename TO, int WAVES_M, int WAVES_N>
+template <typename T, typename TO, int WAVES_M, int WAVES_N, int EPI>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_v2_kernel(const KArgs p) {
-  gemm_body_v2<T, TO, WAVES_M, WAVES_N, false>(p);
+  gemm_body_v2<T, TO, WAVES_M, WAVES_N, false, EPI>(p);
 }
 template <typename T, typename TO, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(const KArgs p) {
-  gemm_body_v2<T, TO, WAVES_M, WAVES_N, true>(p);
+  gemm_body_v2<T, TO, WAVES_M, WAVES_N, true, 0>(p);
 }
-
 
 // =====================================================================================================
 // v3: 256x256 tile, 8 waves (2 x 4, each 128 x 64 = 8 x 4 MFMA fragments), for N > 128.
@@ -727,7 +721,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(c
 // WAVES_N = 4: 256x256 tile, 8 waves, 4-slot ring (128 KiB), one workgroup per CU   -- compute-heavy shapes
 // WAVES_N = 2: 256x128 tile, 4 waves, 3-slot ring ( 72 KiB), TWO workgroups per CU  -- output-heavy shapes (small K, wide N):
 //              one workgroup's epilogue (stores) overlaps the other's K loop instead of idling the matrix cores.
-template <typename T, typename TO, bool CONV, int WAVES_N>
+// EPI (compile time, keeps the fully unrolled epilogue small enough for the instruction cache):
+//   0 linear (+bias, +residual, optional ReLU), 2 sigmoid, 3 tanh, 4 sigmoid & r*h, 5 tanh & GRU blend  (= SR_ACT_* codes; 1 = ReLU folds into 0)
+template <typename T, typename TO, bool CONV, int WAVES_N, int EPI>
 __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   constexpr int BM = 256, BN = 64 * WAVES_N, WAVES_M = 2, NW = WAVES_M * WAVES_N;
   constexpr int EPC = 16 / (int)sizeof(T), BK = 4 * EPC;
@@ -867,7 +863,8 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   auto rdA = [&](int slot, int i) { return *reinterpret_cast<const Frag<T>*>(smem + slot * SLOT + a_off + i * 16 * 64); };
   auto rdB = [&](int slot, int j) { return *reinterpret_cast<const Frag<T>*>(smem + slot * SLOT + b_off + j * 16 * 64); };
 
-  const bool two = (p.act == SR_ACT_SIGMOID_MUL || p.act == SR_ACT_TANH_BLEND);
+  constexpr bool two = (EPI == SR_ACT_SIGMOID_MUL || EPI == SR_ACT_TANH_BLEND);
+  const bool relu = (p.act == SR_ACT_RELU);
   const int Nv = (p.N + 3) & ~3;
   const TO* const zeros = reinterpret_cast<const TO*>(p.zero_page);
 
@@ -948,37 +945,32 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += rv[r];
         }
-        switch (p.act) {
-          case SR_ACT_RELU:
+        if constexpr (EPI == 0) {
+          if (relu) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            break;
-          case SR_ACT_SIGMOID:
+          }
+        } else if constexpr (EPI == SR_ACT_SIGMOID) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
-            break;
-          case SR_ACT_TANH:
+          for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
+        } else if constexpr (EPI == SR_ACT_TANH) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
-            break;
-          case SR_ACT_SIGMOID_MUL: {
-            float h[4];
-            load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
+          for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
+        } else if constexpr (EPI == SR_ACT_SIGMOID_MUL) {
+          float h[4];
+          load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = sigmoidf_(v[r]); o2[r] = v[r] * h[r]; }
-          } break;
-          case SR_ACT_TANH_BLEND: {
-            float h[4], z[4];
-            load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
-            load4<TO>(ok ? (const TO*)p.aux2 + m * p.ldc + n : zeros, z);
+          for (int r = 0; r < 4; ++r) { v[r] = sigmoidf_(v[r]); o2[r] = v[r] * h[r]; }
+        } else if constexpr (EPI == SR_ACT_TANH_BLEND) {
+          float h[4], z[4];
+          load4<TO>(ok ? (const TO*)p.aux1 + m * p.ldc + n : zeros, h);
+          load4<TO>(ok ? (const TO*)p.aux2 + m * p.ldc + n : zeros, z);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float c = tanhf_(v[r]);
-              o2[r] = c;
-              v[r] = (1.f - z[r]) * h[r] + z[r] * c;
-            }
-          } break;
-          default: break;
+          for (int r = 0; r < 4; ++r) {
+            const float c = tanhf_(v[r]);
+            o2[r] = c;
+            v[r] = (1.f - z[r]) * h[r] + z[r] * c;
+          }
         }
         if (STAGED && !two) {
           store4<TO>(reinterpret_cast<TO*>(stg + frow * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8), v);
@@ -1133,10 +1125,10 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   }
 }
 
+template <typename T, typename TO, int WAVES_N, int EPI>
+__global__ __launch_bounds__(128 * WAVES_N, 2) void gemm_nt_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, false, WAVES_N, EPI>(p); }
 template <typename T, typename TO, int WAVES_N>
-__global__ __launch_bounds__(128 * WAVES_N, 2) void gemm_nt_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, false, WAVES_N>(p); }
-template <typename T, typename TO, int WAVES_N>
-__global__ __launch_bounds__(128 * WAVES_N, 2) void conv_igemm_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, true, WAVES_N>(p); }
+__global__ __launch_bounds__(128 * WAVES_N, 2) void conv_igemm_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, true, WAVES_N, 0>(p); }
 
 inline bool use_v1() {
   static const bool v1 = [] { const char* e = getenv("SR_GEMM_V1"); return e && e[0] == '1'; }();
@@ -1151,6 +1143,15 @@ inline int num_cus() {
   return n;
 }
 
+template <typename T, typename TO, int WM, int WN, int EPI>
+int launch_v2e(const KArgs& k, unsigned grid, size_t lds, hipStream_t st) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<T, TO, WM, WN, EPI>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return SR_ERR_LAUNCH;
+  hipLaunchKernelGGL((gemm_nt_v2_kernel<T, TO, WM, WN, EPI>), dim3(grid), dim3(WM * WN * 64), lds, st, k);
+  return SR_OK;
+}
+
 template <typename T, typename TO, int WM, int WN>
 int launch_v2(const KArgs& k, hipStream_t st) {
   constexpr int BM = WM * 64, BN = WN * 64;
@@ -1159,17 +1160,22 @@ int launch_v2(const KArgs& k, hipStream_t st) {
   const size_t lds = 3 * (BM + BN) * 128;
   const long ntiles = gm * gn;
   const unsigned grid = (unsigned)(ntiles < num_cus() ? ntiles : num_cus());
+  int rc = SR_OK;
   if (k.cv.on) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v2_kernel<T, TO, WM, WN>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return SR_ERR_LAUNCH;
     hipLaunchKernelGGL((conv_igemm_v2_kernel<T, TO, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, st, k);
   } else {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<T, TO, WM, WN>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return SR_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_nt_v2_kernel<T, TO, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, st, k);
+    switch (k.act) {
+      case SR_ACT_SIGMOID: rc = launch_v2e<T, TO, WM, WN, SR_ACT_SIGMOID>(k, grid, lds, st); break;
+      case SR_ACT_TANH: rc = launch_v2e<T, TO, WM, WN, SR_ACT_TANH>(k, grid, lds, st); break;
+      case SR_ACT_SIGMOID_MUL: rc = launch_v2e<T, TO, WM, WN, SR_ACT_SIGMOID_MUL>(k, grid, lds, st); break;
+      case SR_ACT_TANH_BLEND: rc = launch_v2e<T, TO, WM, WN, SR_ACT_TANH_BLEND>(k, grid, lds, st); break;
+      default: rc = launch_v2e<T, TO, WM, WN, 0>(k, grid, lds, st); break;
+    }
   }
+  if (rc != SR_OK) return rc;
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -1177,6 +1183,16 @@ int launch_v2(const KArgs& k, hipStream_t st) {
 inline bool use_v3() {
   static const bool off = [] { const char* e = getenv("SR_GEMM_NO_V3"); return e && e[0] == '1'; }();
   return !off && !use_v1();
+}
+
+template <typename T, typename TO, int WN, int EPI>
+int launch_v3e(const KArgs& k, unsigned grid, size_t lds, hipStream_t st) {
+  constexpr int NTHR = 128 * WN;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v3_kernel<T, TO, WN, EPI>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return SR_ERR_LAUNCH;
+  hipLaunchKernelGGL((gemm_nt_v3_kernel<T, TO, WN, EPI>), dim3(grid), dim3(NTHR), lds, st, k);
+  return SR_OK;
 }
 
 template <typename T, typename TO, int WN>
@@ -1189,17 +1205,24 @@ int launch_v3(const KArgs& k_in, hipStream_t st) {
   const size_t lds = NSLOT * (256 + BN) * 64 + 2 * WN * 2048;
   const long ntiles = gm * gn, cap = (long)num_cus() * WG_PER_CU;
   const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+  int rc = SR_OK;
   if (k.cv.on) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v3_kernel<T, TO, WN>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return SR_ERR_LAUNCH;
     hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN>), dim3(grid), dim3(NTHR), lds, st, k);
+  } else if constexpr (WN == 2) {
+    rc = launch_v3e<T, TO, WN, 0>(k, grid, lds, st);          // narrow tiles: linear epilogue only (caller guarantees)
   } else {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v3_kernel<T, TO, WN>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return SR_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_nt_v3_kernel<T, TO, WN>), dim3(grid), dim3(NTHR), lds, st, k);
+    switch (k.act) {
+      case SR_ACT_SIGMOID: rc = launch_v3e<T, TO, WN, SR_ACT_SIGMOID>(k, grid, lds, st); break;
+      case SR_ACT_TANH: rc = launch_v3e<T, TO, WN, SR_ACT_TANH>(k, grid, lds, st); break;
+      case SR_ACT_SIGMOID_MUL: rc = launch_v3e<T, TO, WN, SR_ACT_SIGMOID_MUL>(k, grid, lds, st); break;
+      case SR_ACT_TANH_BLEND: rc = launch_v3e<T, TO, WN, SR_ACT_TANH_BLEND>(k, grid, lds, st); break;
+      default: rc = launch_v3e<T, TO, WN, 0>(k, grid, lds, st); break;
+    }
   }
+  if (rc != SR_OK) return rc;
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -1236,7 +1259,9 @@ int launch_cfg(const KArgs& k, hipStream_t st) {
 template <typename T, typename TO>
 int launch(const KArgs& k, hipStream_t st) {
   if (use_v1()) return k.N <= 64 ? launch_cfg<T, TO, 4, 1>(k, st) : launch_cfg<T, TO, 2, 2>(k, st);
-  if (k.N > 64 && use_v3()) return (k.N <= 128 || prefer_narrow(k)) ? launch_v3<T, TO, 2>(k, st) : launch_v3<T, TO, 4>(k, st);
+  const bool linear = k.act == SR_ACT_NONE || k.act == SR_ACT_RELU;
+  if (k.N > 128 && use_v3() && !(linear && prefer_narrow(k))) return launch_v3<T, TO, 4>(k, st);
+  if (k.N > 64 && use_v3() && linear) return launch_v3<T, TO, 2>(k, st);
   return k.N <= 64 ? launch_v2<T, TO, 4, 1>(k, st) : launch_v2<T, TO, 4, 2>(k, st);
 }
 
