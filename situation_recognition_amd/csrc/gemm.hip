@@ -1082,6 +1082,8 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     // a[i] dies after its two MFMAs and is reloaded for step s+1 on the spot; b[0], b[1] (dead after sweep 0) are reloaded in
     // sweep 1 as well; only b[2], b[3] of the next step need spare registers (bs).  The 4 DMA instructions of step s+4
     // are issued in sweep 0.
+    // (Specialising this block four ways on (roll, do_issue) to drop the uniform branches made hipcc spill ~200 registers
+    //  and ran 20x slower; the branches stay.)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       mma<T>(b[0], a[i], acc[0][i]);

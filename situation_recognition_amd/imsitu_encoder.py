@@ -6,10 +6,55 @@ them on the GPU by verb id instead of looping over the batch in Python
 Same ids as the reference: verbs, roles and labels are numbered in first-seen order while walking
 images -> frames -> (role, label); padded role slots hold `num_roles`, padded label slots `num_labels`.
 """
+import random
+
 import torch
+
+_MEAN, _STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def _to_normalised_tensor(img):
+    """ToTensor + Normalize(ImageNet mean/std) of a PIL RGB image -> float32 [3,H,W]."""
+    import numpy as np
+    a = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+    return (a - torch.tensor(_MEAN).view(3, 1, 1)) / torch.tensor(_STD).view(3, 1, 1)
+
+
+def _resize_shorter(img, size):
+    from PIL import Image
+    w, h = img.size
+    if w <= h:
+        nw, nh = size, max(size, int(round(h * size / w)))
+    else:
+        nw, nh = max(size, int(round(w * size / h))), size
+    return img.resize((nw, nh), Image.BILINEAR)
+
+
+def train_transform(img):
+    """reference imsitu_encoder.py:21-29: Resize(224) -> RandomCrop(224) -> RandomHorizontalFlip -> ToTensor -> Normalize
+    (PIL-only restatement: torchvision is not a dependency here)."""
+    from PIL import Image
+    img = _resize_shorter(img, 224)
+    w, h = img.size
+    x0, y0 = random.randint(0, w - 224), random.randint(0, h - 224)
+    img = img.crop((x0, y0, x0 + 224, y0 + 224))
+    if random.random() < 0.5:
+        img = img.transpose(Image.FLIP_LEFT_RIGHT)
+    return _to_normalised_tensor(img)
+
+
+def dev_transform(img):
+    """reference imsitu_encoder.py:31-36: Resize(224) -> CenterCrop(224) -> ToTensor -> Normalize."""
+    img = _resize_shorter(img, 224)
+    w, h = img.size
+    x0, y0 = int(round((w - 224) / 2.0)), int(round((h - 224) / 2.0))
+    return _to_normalised_tensor(img.crop((x0, y0, x0 + 224, y0 + 224)))
 
 
 class imsitu_encoder:
+    train_transform = staticmethod(train_transform)
+    dev_transform = staticmethod(dev_transform)
+
     def __init__(self, train_set=None, quiet=False):
         self.max_label_count = 3
         self.verb_list, self.role_list, self.label_list = [], [], []
