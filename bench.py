@@ -211,8 +211,18 @@ def main():
         tsum, fsum = sum(t for t, _ in conv), sum(f for _, f in conv)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         ach = fsum / tsum / 1e12
+        # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately on this exact
+        # command: profiles/conv_traffic.json records them with the gfx950 corrections); null for any other configuration
+        traffic = None
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "conv_traffic.json")))
+            c = t["config"]
+            if (c["backbone"], c["per_gpu_batch"], c["dtype"], c["res"]) == (args.backbone, B, args.dtype, args.res):
+                traffic = round(t["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": None,
+                           "frac": round(ach / peak, 4), "traffic": traffic,
                            "kernel": "conv_igemm_kernel (backbone implicit-GEMM convolutions, %d launches per pass)" % len(conv),
                            "avg_launch_ms": round(1e3 * tsum / len(conv), 4),
                            "alg_gflop_per_launch": round(fsum / len(conv) / 1e9, 3)}
