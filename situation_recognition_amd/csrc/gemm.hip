@@ -1232,7 +1232,16 @@ int launch_v3(const KArgs& k_in, hipStream_t st) {
 // 256x128 / two workgroups per CU when the tile's K loop is short relative to its epilogue (output-heavy)
 inline bool prefer_narrow(const KArgs& k) {
   static const int force = [] { const char* e = getenv("SR_GEMM_NARROW"); return e ? atoi(e) : -1; }();
-  return force > 0;   // measured: no gain over the 256x256 tile on output-heavy shapes; kept for N <= 128 and experiments
+  if (force > 0) return true;
+  // Wave quantisation: with few tiles per CU the last round of 256x256 tiles leaves most CUs idle (e.g. 294 tiles on 256 CUs
+  // = 57 % busy).  256x128 tiles run two workgroups per CU (512 slots) and halve the granule; take them when that fills
+  // the chip noticeably better.  (On long, output-heavy launches the two shapes measured within 3 % of each other.)
+  const long cus = num_cus();
+  const long tw = (((long)k.M + 255) / 256) * ((k.N + 255) / 256), tn = (((long)k.M + 255) / 256) * ((k.N + 127) / 128);
+  if (tw >= 6 * cus) return false;
+  const double ew = (double)tw / (double)(((tw + cus - 1) / cus) * cus);
+  const double en = (double)tn / (double)(((tn + 2 * cus - 1) / (2 * cus)) * (2 * cus));
+  return en > ew + 0.08;
 }
 
 inline int tile_m_for(int N) { return use_v1() ? (N <= 64 ? 256 : 128) : 256; }

@@ -343,15 +343,18 @@ class _GGNNFunction(torch.autograd.Function):
         gT = lambda p: shadow.get(p, dt, transposed=True)
         D = Wp.shape[0]
         dev = dh.device
-        gW = {k: torch.zeros(D, D, device=dev, dtype=torch.float32) for k in ("Wp", "Wz", "Uz", "Wr", "Ur", "Wh", "Uh")}
+        # Weight-gradient accumulators.  The four z/r matrices come out of ONE GEMM per step, [dz^T; dr^T] x [h^T; n^T]
+        # (4096 x 4096 = 256 tiles: the whole chip, instead of four 64-tile launches), the two candidate matrices out of
+        # dc^T x [n^T; (r*h)^T]; blocks are sliced apart at the end.
+        gZR = torch.zeros(2 * D, 2 * D, device=dev, dtype=torch.float32)      # rows: z | r ; cols: U (h) | W (n)
+        gC = torch.zeros(D, 2 * D, device=dev, dtype=torch.float32)           # cols: W_h (n) | U_h (r*h)
+        gP = torch.zeros(D, D, device=dev, dtype=torch.float32)
         gb = {k: torch.zeros(D, device=dev, dtype=torch.float32) for k in ("p", "z", "r", "h")}
         dh = dh.contiguous()
         if dh.dtype != dt:
             dh = ops.cast(dh, dt)
-
-        def acc(name, dyT, xT):
-            ops.gemm([(dyT, xT)], res=gW[name], out=gW[name], out_f32=True)
-
+        M = saved[0].shape[0]
+        Mp = (M + kp - 1) // kp * kp
         for t in reversed(range(steps)):
             h, agg, n, z, r, rh, c = saved[7 * t: 7 * t + 7]
             dc, dz, dacc = ops.gru_bwd1(dh, z, c, h)
@@ -364,20 +367,23 @@ class _GGNNFunction(torch.autograd.Function):
             else:
                 dagg = ops.gemm([(dn, gT(Wp))])
                 dh = ops.aggregate(dagg, adj, idx, R, transpose=True, add=dacc)
-            # weight / bias gradients: dW = dY^T X as NT GEMMs over transposed copies; the bias
-            # gradients (column sums) are reduced inside the transpose kernel
+            # transposed operands (dW = dY^T X as NT GEMMs); bias gradients (column sums) are reduced inside the transpose kernel
+            YT = torch.empty((2, D, Mp), device=dev, dtype=dt)         # dz^T, dr^T
+            XT = torch.empty((3, D, Mp), device=dev, dtype=dt)         # h^T, n^T, (r*h)^T
+            ops.transpose(dz, colsum=gb["z"], pad_to=kp, out=YT[0])
+            ops.transpose(dr, colsum=gb["r"], pad_to=kp, out=YT[1])
             dcT = ops.transpose(dc, colsum=gb["h"], pad_to=kp)
-            dzT = ops.transpose(dz, colsum=gb["z"], pad_to=kp)
-            drT = ops.transpose(dr, colsum=gb["r"], pad_to=kp)
             dnT = ops.transpose(dn, colsum=gb["p"], colsum_scale=1.0 if verb else float(R), pad_to=kp)
-            nT, hT, rhT = ops.transpose(n, pad_to=kp), ops.transpose(h, pad_to=kp), ops.transpose(rh, pad_to=kp)
-            aggT = hT if verb else ops.transpose(agg, pad_to=kp)
-            acc("Wh", dcT, nT); acc("Uh", dcT, rhT)
-            acc("Wz", dzT, nT); acc("Uz", dzT, hT)
-            acc("Wr", drT, nT); acc("Ur", drT, hT)
-            acc("Wp", dnT, aggT)
-        grads = (gW["Wp"], gb["p"], gW["Wz"], gb["z"], gW["Uz"], gb["z"].clone(), gW["Wr"], gb["r"], gW["Ur"], gb["r"].clone(),
-                 gW["Wh"], gb["h"], gW["Uh"], gb["h"].clone())
+            ops.transpose(h, pad_to=kp, out=XT[0])
+            ops.transpose(n, pad_to=kp, out=XT[1])
+            ops.transpose(rh, pad_to=kp, out=XT[2])
+            aggT = XT[0] if verb else ops.transpose(agg, pad_to=kp)
+            ops.gemm([(YT.view(2 * D, Mp), XT[0:2].view(2 * D, Mp))], res=gZR, out=gZR, out_f32=True)
+            ops.gemm([(dcT, XT[1:3].view(2 * D, Mp))], res=gC, out=gC, out_f32=True)
+            ops.gemm([(dnT, aggT)], res=gP, out=gP, out_f32=True)
+        blk = lambda g_, i, j: g_[i * D:(i + 1) * D, j * D:(j + 1) * D].contiguous()
+        grads = (gP, gb["p"], blk(gZR, 0, 1), gb["z"], blk(gZR, 0, 0), gb["z"].clone(), blk(gZR, 1, 1), gb["r"], blk(gZR, 1, 0),
+                 gb["r"].clone(), blk(gC, 0, 0), gb["h"], blk(gC, 0, 1), gb["h"].clone())
         return (dh, None, None, None, None, None, None) + grads
 
 

@@ -220,14 +220,18 @@ def gru_bwd2(drh, r, h, dh_acc):
     return dr
 
 
-def transpose(x, out_dtype=None, colsum=None, colsum_scale=1.0, pad_to=1):
-    """[R,C] (rows may be strided) -> [C, Rpad] with Rpad = R rounded up to `pad_to`, zero filled."""
+def transpose(x, out_dtype=None, colsum=None, colsum_scale=1.0, pad_to=1, out=None):
+    """[R,C] (rows may be strided) -> [C, Rpad] with Rpad = R rounded up to `pad_to`, zero filled.
+    `out`: optional preallocated contiguous [C, Rpad] destination (e.g. a slice of a stacked operand)."""
     require_gpu(colsum)
     R, Cc = x.shape
     if x.stride(1) != 1 or not x.is_cuda:
         raise L.SrError("transpose: rows must be contiguous CUDA memory")
     Rp = (R + pad_to - 1) // pad_to * pad_to
-    out = torch.empty((Cc, Rp), device=x.device, dtype=out_dtype or x.dtype)
+    if out is None:
+        out = torch.empty((Cc, Rp), device=x.device, dtype=out_dtype or x.dtype)
+    elif tuple(out.shape) != (Cc, Rp) or not out.is_contiguous():
+        raise L.SrError("transpose: bad `out`")
     check(lib().sr_transpose(x.data_ptr(), x.stride(0), out.data_ptr(), R, Cc, Rp, dtype_code(x.dtype), dtype_code(out.dtype),
                              ptr(_f32(colsum, "colsum")), float(colsum_scale), stream()), "sr_transpose")
     return out
