@@ -723,16 +723,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(c
 //              one workgroup's epilogue (stores) overlaps the other's K loop instead of idling the matrix cores.
 // EPI (compile time, keeps the fully unrolled epilogue small enough for the instruction cache):
 //   0 linear (+bias, +residual, optional ReLU), 2 sigmoid, 3 tanh, 4 sigmoid & r*h, 5 tanh & GRU blend  (= SR_ACT_* codes; 1 = ReLU folds into 0)
+// WAVES_N = 1: 256x64 tile, 4 waves stacked along M (each 64x64 = 4x4 fragments), 3-slot ring (60 KiB), two workgroups per CU -- N <= 64
 template <typename T, typename TO, bool CONV, int WAVES_N, int EPI>
 __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
-  constexpr int BM = 256, BN = 64 * WAVES_N, WAVES_M = 2, NW = WAVES_M * WAVES_N;
+  constexpr int WAVES_M = WAVES_N == 1 ? 4 : 2, FM = 16 / WAVES_M;   // FM: 16-row fragments per wave along M
+  constexpr int BM = 256, BN = 64 * WAVES_N, NW = WAVES_M * WAVES_N;
   constexpr int EPC = 16 / (int)sizeof(T), BK = 4 * EPC;
   constexpr int NSLOT = WAVES_N == 4 ? 4 : 3;
   constexpr int SLOT = (BM + BN) * 64, STG_OFF = NSLOT * SLOT;
   constexpr int A_PER = (BM / 16) / NW, B_PER = (BN / 16) / NW;
   constexpr int L = A_PER + B_PER;                      // DMA instructions per lane per step
   constexpr bool STAGED = sizeof(TO) == 2;              // 16-bit outputs leave through a per-wave LDS staging strip
-  constexpr int S = STAGED ? 16 : 32;                   // store instructions per lane per epilogue (single output)
+  constexpr int S = STAGED ? 2 * FM : 4 * FM;           // store instructions per lane per epilogue (single output)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -849,16 +851,16 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     }
   };
 
-  f32x4_t acc[4][8];  // [n-fragment j][m-fragment i]
+  f32x4_t acc[4][FM];  // [n-fragment j][m-fragment i]
   auto clear_acc = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < FM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   };
   clear_acc();
 
-  const int a_off = (wm * 128 + (lane & 15)) * 64 + fsw;
+  const int a_off = (wm * FM * 16 + (lane & 15)) * 64 + fsw;
   const int b_off = BM * 64 + (wn * 64 + (lane & 15)) * 64 + fsw;
   auto rdA = [&](int slot, int i) { return *reinterpret_cast<const Frag<T>*>(smem + slot * SLOT + a_off + i * 16 * 64); };
   auto rdB = [&](int slot, int j) { return *reinterpret_cast<const Frag<T>*>(smem + slot * SLOT + b_off + j * 16 * 64); };
@@ -894,7 +896,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
           const int n = n0 + wn * 64 + j * 16 + fgrp * 4 + r;
           const float e = p.escale[n < p.N ? n : p.N - 1];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[j][i][r] *= e;
+          for (int i = 0; i < FM; ++i) acc[j][i][r] *= e;
         }
     }
     if (want_stats) {
@@ -907,8 +909,8 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         const int nj = n0 + wn * 64 + j * 16 + fgrp * 4;
         const bool nok = nj < Nv;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const bool ok = nok && (m0 + wm * 128 + i * 16 + frow < p.M);
+        for (int i = 0; i < FM; ++i) {
+          const bool ok = nok && (m0 + wm * FM * 16 + i * 16 + frow < p.M);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = ok ? acc[j][i][r] + bv[j][r] : 0.f;
@@ -929,8 +931,8 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     // pass 2, i-major: one 16-row x 64-column strip of the wave's tile at a time
     if (!p.no_store) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const long m = m0 + wm * 128 + i * 16 + frow;
+    for (int i = 0; i < FM; ++i) {
+      const long m = m0 + wm * FM * 16 + i * 16 + frow;
       char* stg = smem + STG_OFF + wave * 2048;             // per-wave [16 rows][64 cols] 16-bit strip; 16-B chunk c of row r at c ^ (r & 7)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -986,7 +988,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int r16 = h * 8 + (el >> 3), c8 = (el & 7) * 8;
-          const long mm = m0 + wm * 128 + i * 16 + r16;
+          const long mm = m0 + wm * FM * 16 + i * 16 + r16;
           const int nn = n0 + wn * 64 + c8;
           const uint4 val = *reinterpret_cast<const uint4*>(stg + r16 * 128 + (((el & 7) ^ (r16 & 7)) << 4));
           const bool okk = (mm < p.M) && (nn + 8 <= Nv);
@@ -1011,7 +1013,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   // at once: HBM idles during the K loops and is oversubscribed during the epilogues (measured: store phase as long
   // as the K loop on output-heavy shapes).  Starting workgroup g with a delay of (g mod 8)/8 of a tile period keeps
   // only 1/8 of the chip in its store phase at any time.  Purely a timing nudge: no correctness dependence.
-  if (WAVES_N == 2 && my_tiles >= 4 && !(p.debug & 8)) {
+  if (WAVES_N <= 2 && my_tiles >= 4 && !(p.debug & 8)) {
     // two workgroups share a CU (second dispatch round = upper half of the grid): offset them by half a tile period so
     // that one is in its K loop while the other drains its stores
     const unsigned long long period = (unsigned long long)nkt * 2300ull + 16000ull;   // cycles per tile, roughly
@@ -1034,9 +1036,9 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   if (issued >= 4) wait_vm<3 * L>(); else if (issued == 3) wait_vm<2 * L>(); else if (issued == 2) wait_vm<L>(); else wait_vm<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  Frag<T> a[8], b[4], bs[2];
+  Frag<T> a[FM], b[4], bs[2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = rdA(0, i);
+  for (int i = 0; i < FM; ++i) a[i] = rdA(0, i);
 #pragma unroll
   for (int j = 0; j < 4; ++j) b[j] = rdB(0, j);
   bs[0] = b[2]; bs[1] = b[3];
@@ -1085,15 +1087,19 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     // (Specialising this block four ways on (roll, do_issue) to drop the uniform branches made hipcc spill ~200 registers
     //  and ran 20x slower; the branches stay.)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < FM; ++i) {
       mma<T>(b[0], a[i], acc[0][i]);
       mma<T>(b[1], a[i], acc[1][i]);
       if (i < L && do_issue) issue_piece(i);
-      if (roll && i == 4) bs[0] = rdB(nslot, 2);
-      if (roll && i == 6) bs[1] = rdB(nslot, 3);
+      if (roll && i == FM / 2) bs[0] = rdB(nslot, 2);
+      if (roll && i == FM / 2 + FM / 4) bs[1] = rdB(nslot, 3);
+    }
+    if (do_issue) {
+#pragma unroll
+      for (int q = FM; q < L; ++q) issue_piece(q);   // (only when a lane has more DMA pieces than row fragments)
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < FM; ++i) {
       mma<T>(b[2], a[i], acc[2][i]);
       mma<T>(b[3], a[i], acc[3][i]);
       if (roll) {
@@ -1114,7 +1120,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
       clear_acc();
       if (has_next) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = rdA(nslot, i);
+        for (int i = 0; i < FM; ++i) a[i] = rdA(nslot, i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = rdB(nslot, j);
       }
@@ -1122,15 +1128,15 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     }
   }
   if (stamp && blockIdx.x < 256 && (threadIdx.x & 63) == 0) {
-    unsigned long long* o = g_stamps + (blockIdx.x * 8 + wave) * 8;
+    unsigned long long* o = g_stamps + ((blockIdx.x * 8 + wave) & 2047) * 8;
     o[0] = tw; o[1] = tb; o[2] = 0; o[3] = tm_; o[4] = te; o[5] = (unsigned long long)total;
   }
 }
 
 template <typename T, typename TO, int WAVES_N, int EPI>
-__global__ __launch_bounds__(128 * WAVES_N, 2) void gemm_nt_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, false, WAVES_N, EPI>(p); }
+__global__ __launch_bounds__(WAVES_N == 1 ? 256 : 128 * WAVES_N, 2) void gemm_nt_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, false, WAVES_N, EPI>(p); }
 template <typename T, typename TO, int WAVES_N>
-__global__ __launch_bounds__(128 * WAVES_N, 2) void conv_igemm_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, true, WAVES_N, 0>(p); }
+__global__ __launch_bounds__(WAVES_N == 1 ? 256 : 128 * WAVES_N, 2) void conv_igemm_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, true, WAVES_N, 0>(p); }
 
 inline bool use_v1() {
   static const bool v1 = [] { const char* e = getenv("SR_GEMM_V1"); return e && e[0] == '1'; }();
@@ -1182,6 +1188,10 @@ int launch_v2(const KArgs& k, hipStream_t st) {
   return SR_OK;
 }
 
+inline bool no_v3_n64() {
+  static const bool off = [] { const char* e = getenv("SR_GEMM_NO_V3_N64"); return e && e[0] == '1'; }();
+  return off;
+}
 inline bool use_v3() {
   static const bool off = [] { const char* e = getenv("SR_GEMM_NO_V3"); return e && e[0] == '1'; }();
   return !off && !use_v1();
@@ -1189,7 +1199,7 @@ inline bool use_v3() {
 
 template <typename T, typename TO, int WN, int EPI>
 int launch_v3e(const KArgs& k, unsigned grid, size_t lds, hipStream_t st) {
-  constexpr int NTHR = 128 * WN;
+  constexpr int NTHR = WN == 1 ? 256 : 128 * WN;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v3_kernel<T, TO, WN, EPI>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr != hipSuccess) return SR_ERR_LAUNCH;
@@ -1201,10 +1211,10 @@ template <typename T, typename TO, int WN>
 int launch_v3(const KArgs& k_in, hipStream_t st) {
   KArgs k = k_in;
   for (int i = 0; i < 3; ++i) k.nk[i] *= 2;  // host counts 128-byte K-tiles; v3 steps are 64 bytes
-  constexpr int BN = 64 * WN, NSLOT = WN == 4 ? 4 : 3, NTHR = 128 * WN, WG_PER_CU = WN == 4 ? 1 : 2;
+  constexpr int BN = 64 * WN, NSLOT = WN == 4 ? 4 : 3, NTHR = WN == 1 ? 256 : 128 * WN, WG_PER_CU = WN == 4 ? 1 : 2;
   const long gm = ((long)k.M + 255) / 256, gn = (k.N + BN - 1) / BN;
   if (gm * gn > 0x7fffffffL) return SR_ERR_ARG;
-  const size_t lds = NSLOT * (256 + BN) * 64 + 2 * WN * 2048;
+  const size_t lds = NSLOT * (256 + BN) * 64 + (NTHR / 64) * 2048;
   const long ntiles = gm * gn, cap = (long)num_cus() * WG_PER_CU;
   const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
   int rc = SR_OK;
@@ -1213,7 +1223,7 @@ int launch_v3(const KArgs& k_in, hipStream_t st) {
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return SR_ERR_LAUNCH;
     hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN>), dim3(grid), dim3(NTHR), lds, st, k);
-  } else if constexpr (WN == 2) {
+  } else if constexpr (WN <= 2) {
     rc = launch_v3e<T, TO, WN, 0>(k, grid, lds, st);          // narrow tiles: linear epilogue only (caller guarantees)
   } else {
     switch (k.act) {
@@ -1273,6 +1283,7 @@ int launch(const KArgs& k, hipStream_t st) {
   const bool linear = k.act == SR_ACT_NONE || k.act == SR_ACT_RELU;
   if (k.N > 128 && use_v3() && !(linear && prefer_narrow(k))) return launch_v3<T, TO, 4>(k, st);
   if (k.N > 64 && use_v3() && linear) return launch_v3<T, TO, 2>(k, st);
+  if (k.N <= 64 && use_v3() && linear && !no_v3_n64()) return launch_v3<T, TO, 1>(k, st);
   return k.N <= 64 ? launch_v2<T, TO, 4, 1>(k, st) : launch_v2<T, TO, 4, 2>(k, st);
 }
 
@@ -1316,6 +1327,7 @@ extern "C" int sr_debug_stamps(unsigned long long* host_out, int count) {
 
 extern "C" int sr_gemm_stats_tiles(int M, int N) {
   if (!use_v1() && N > 64 && use_v3()) return 2 * ((M + 255) / 256);  // v3: one partial row per 128-row wave group
+  if (!use_v1() && N <= 64 && use_v3() && !no_v3_n64()) return 4 * ((M + 255) / 256);  // 256x64 tiles: four 64-row wave groups
   const int bm = tile_m_for(N);
   return (M + bm - 1) / bm;
 }
@@ -1384,7 +1396,7 @@ extern "C" int sr_conv2d(const sr_conv_args* a, int dtype, void* stream) {
   k.C = a->y; k.ldc = a->Cout; k.bias = a->bias; k.bias_scale = 1.f;
   k.res = a->res; k.ldres = a->Cout; k.stats = a->stats;
   k.escale = a->escale; k.no_store = a->no_store;
-  if ((a->escale || a->no_store) && !(a->Cout > 64 && use_v3())) return SR_ERR_UNSUPPORTED;
+  if ((a->escale || a->no_store) && !use_v3()) return SR_ERR_UNSUPPORTED;
   if (a->no_store && !a->stats) return SR_ERR_ARG;
   return dispatch(k, dtype, 0, (hipStream_t)stream);
 }

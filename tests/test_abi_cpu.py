@@ -36,7 +36,7 @@ def test_argument_validation_needs_no_gpu(libpath):
     a.npairs, a.M, a.N = 1, 4, 4
     assert l.sr_gemm(ctypes.byref(a), 7, None) in (-1, -2)
     assert l.sr_conv2d(None, 1, None) == -1
-    assert l.sr_gemm_stats_tiles(1000, 64) == 4                   # one partial row per 256-row tile
+    assert l.sr_gemm_stats_tiles(1000, 64) == 16                  # 256x64 tiles of four 64-row wave groups
     assert l.sr_gemm_stats_tiles(1000, 256) == 8                  # 256-row tiles of 128-row wave groups: one row each
     assert l.sr_gemm_stats_tiles(1000, 128) == 8
 
