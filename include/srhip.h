@@ -111,7 +111,7 @@ int sr_stem_prep(const float* img, void* out, int B, int H, int W, int dtype, vo
 int sr_bn_finalize(const float* stats, int tiles, int C, int64_t count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps,
                    float* scale, float* shift, double* scratch, int scratch_rows, void* stream);
-/* scratch: caller-owned fp64 workspace [scratch_rows][2][C] (scratch_rows >= 1; 256 rows use full parallelism)
+/* scratch: caller-owned fp64 workspace [scratch_rows][2][C] (scratch_rows >= 1; 1024 rows use full parallelism)
  * for the deterministic two-stage reduction of the partials. */
 /* y = [relu]( x*scale[c] + shift[c] (+ res) ), rows x C, in place allowed. */
 int sr_bn_apply(const void* x, const float* scale, const float* shift, const void* res, void* y,

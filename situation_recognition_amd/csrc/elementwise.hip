@@ -66,17 +66,28 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
   }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ scratch, int chunks, int C, double inv_count, double unbias,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
-                                   float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// Stage B: 64 channels x 16 chunk-groups per workgroup; fixed summation order (deterministic).
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ scratch, int chunks, int C, double inv_count,
+                                                           double unbias, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ rmean,
+                                                           float* __restrict__ rvar, float momentum, float eps,
+                                                           float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double red[2][16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   double s1 = 0.0, s2 = 0.0;
-  for (int t = 0; t < chunks; ++t) {
-    s1 += scratch[((long)t * 2 + 0) * C + c];
-    s2 += scratch[((long)t * 2 + 1) * C + c];
+  if (c < C) {
+    for (int t = ty; t < chunks; t += 16) {
+      s1 += scratch[((long)t * 2 + 0) * C + c];
+      s2 += scratch[((long)t * 2 + 1) * C + c];
+    }
   }
+  red[0][ty][tx] = s1;
+  red[1][ty][tx] = s2;
+  __syncthreads();
+  if (ty != 0 || c >= C) return;
+  s1 = 0.0; s2 = 0.0;
+  for (int t = 0; t < 16; ++t) { s1 += red[0][t][tx]; s2 += red[1][t][tx]; }
   const double mean = s1 * inv_count;
   double var = s2 * inv_count - mean * mean;  // biased (what normalisation uses)
   if (var < 0.0) var = 0.0;
@@ -283,14 +294,14 @@ extern "C" int sr_bn_finalize(const float* stats, int tiles, int C, int64_t coun
   if (!stats || tiles <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !scale || !shift || !scratch || scratch_rows < 1)
     return SR_ERR_ARG;
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  int chunks = (tiles + 15) / 16;
+  int chunks = (tiles + 31) / 32;   // stage A: >= 32 partial rows per workgroup, up to 1024 workgroups per 64 channels
   if (chunks > scratch_rows) chunks = scratch_rows;
-  if (chunks > 32) chunks = 32;   // stage B walks the chunks serially per channel: keep it short (was 256: 69 us per call)
+  if (chunks > 1024) chunks = 1024;
   const int tpc = (tiles + chunks - 1) / chunks;
   chunks = (tiles + tpc - 1) / tpc;
   hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, stats, tiles, C, tpc,
                      scratch);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, scratch, chunks, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, scratch, chunks, C,
                      1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps, scale, shift);
   SR_CHECK_LAUNCH();
   return SR_OK;

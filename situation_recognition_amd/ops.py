@@ -134,11 +134,11 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
     key = (stats.device, torch.cuda.current_stream().cuda_stream)
     scratch = _BN_SCRATCH.get(key)
     if scratch is None or scratch.shape[2] < Cc:
-        scratch = torch.empty((256, 2, max(Cc, 2048)), device=stats.device, dtype=torch.float64)
+        scratch = torch.empty((1024, 2, max(Cc, 2048)), device=stats.device, dtype=torch.float64)
         _BN_SCRATCH[key] = scratch
     check(lib().sr_bn_finalize(stats.data_ptr(), stats.shape[0], Cc, int(count), gamma.data_ptr(), beta.data_ptr(),
                                ptr(running_mean), ptr(running_var), float(momentum), float(eps), scale.data_ptr(),
-                               shift.data_ptr(), scratch.data_ptr(), 256, stream()), "sr_bn_finalize")
+                               shift.data_ptr(), scratch.data_ptr(), 1024, stream()), "sr_bn_finalize")
     return scale, shift
 
 
