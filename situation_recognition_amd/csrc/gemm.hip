@@ -930,8 +930,26 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     }
     // pass 2, i-major: one 16-row x 64-column strip of the wave's tile at a time
     if (!p.no_store) {
+    // 16-bit outputs with a residual: the residual is NOT fetched in fragment layout (4 scattered columns per lane) but as
+    // whole 16-byte row chunks, coalesced, one strip ahead, and added (+ReLU) after the LDS transpose, on the output rows.
+    constexpr bool ROWRES = STAGED && EPI == 0;
+    const bool rowres = ROWRES && p.res != nullptr;
+    uint4 rnext[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    auto fetch_res = [&](int i, uint4 (&dst)[2]) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r16 = h * 8 + (el >> 3), c8 = (el & 7) * 8;
+        const long mm = m0 + wm * FM * 16 + i * 16 + r16;
+        const int nn = n0 + wn * 64 + c8;
+        const bool okk = (mm < p.M) && (nn + 8 <= Nv);
+        dst[h] = *reinterpret_cast<const uint4*>(okk ? (const char*)((const TO*)p.res + mm * p.ldres + nn) : (const char*)p.zero_page);
+      }
+    };
+    if (rowres) fetch_res(0, rnext);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+      uint4 rcur[2] = {rnext[0], rnext[1]};
+      if (rowres && i + 1 < FM) fetch_res(i + 1, rnext);
       const long m = m0 + wm * FM * 16 + i * 16 + frow;
       char* stg = smem + STG_OFF + wave * 2048;             // per-wave [16 rows][64 cols] 16-bit strip; 16-B chunk c of row r at c ^ (r & 7)
 #pragma unroll
@@ -941,14 +959,14 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         float v[4], o2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] + bv[j][r];
-        if (p.res) {
+        if (p.res && !rowres) {
           float rv[4];
           load4<TO>(ok ? (const TO*)p.res + m * p.ldres + n : zeros, rv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += rv[r];
         }
         if constexpr (EPI == 0) {
-          if (relu) {
+          if (relu && !rowres) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
           }
@@ -990,7 +1008,23 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
           const int r16 = h * 8 + (el >> 3), c8 = (el & 7) * 8;
           const long mm = m0 + wm * FM * 16 + i * 16 + r16;
           const int nn = n0 + wn * 64 + c8;
-          const uint4 val = *reinterpret_cast<const uint4*>(stg + r16 * 128 + (((el & 7) ^ (r16 & 7)) << 4));
+          uint4 val = *reinterpret_cast<const uint4*>(stg + r16 * 128 + (((el & 7) ^ (r16 & 7)) << 4));
+          if constexpr (ROWRES) {
+            if (rowres) {
+              const unsigned* pv_ = reinterpret_cast<const unsigned*>(&val);
+              const unsigned* pr_ = reinterpret_cast<const unsigned*>(&rcur[h]);
+              unsigned ow[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float lo = __uint_as_float(pv_[q] << 16) + __uint_as_float(pr_[q] << 16);
+                float hi = __uint_as_float(pv_[q] & 0xffff0000u) + __uint_as_float(pr_[q] & 0xffff0000u);
+                if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                bf16_t pk[2] = {(bf16_t)lo, (bf16_t)hi};
+                ow[q] = *reinterpret_cast<const unsigned*>(pk);
+              }
+              val = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            }
+          }
           const bool okk = (mm < p.M) && (nn + 8 <= Nv);
           if (okk || nn >= Nv || mm >= p.M) {
             *reinterpret_cast<uint4*>(okk ? (char*)((TO*)p.C + mm * p.ldc + nn) : (char*)p.trash_page + el * 16) = val;

@@ -187,8 +187,7 @@ class resnet(nn.Module):
         self.dtype = dtype
         self.depth = depth
         self._units = None
-        self.two_pass = False          # train-mode BN of output-heavy 1x1 convs in two conv launches (see _unit); measured slower
-                                       # than conv + bn_apply with the current epilogue (1280 vs 1138 ms/step), kept selectable
+        self.two_pass = True           # train-mode BN of output-heavy 1x1 convs in two conv launches (see _unit)
         self._stats_epoch = 0          # bumped whenever a train-mode pass changed running statistics
         self._pending_tracked = 0      # num_batches_tracked increments not yet written to the buffers
         self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_counters())
