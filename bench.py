@@ -200,9 +200,11 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        # Dominant kernel = conv_igemm_kernel (backbone convolutions).  One extra train-mode backbone pass with every
-        # launch bracketed by HIP events on the launch stream; achieved = sum(alg. FLOPs) / sum(durations)
-        # = (average FLOPs per launch) / (average launch duration).
+        # Dominant kernel = conv_igemm_* (backbone convolutions).  One extra train-mode backbone pass with every launch
+        # bracketed by HIP events on the launch stream; achieved = sum(ALGORITHMIC FLOPs) / sum(durations)
+        # = (average algorithmic FLOPs per launch) / (average launch duration).  Algorithmic = 2*M*N*K of each convolution
+        # once (= 23.023 GFLOP per image for ResNet-152): the statistics-only launches of the two-launch
+        # BatchNorm scheme add their time but no FLOPs.
         ops.PROFILE = []
         net.convnet_verbs(img)
         torch.cuda.synchronize()
@@ -223,7 +225,7 @@ def main():
             pass
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": traffic,
-                           "kernel": "conv_igemm_kernel (backbone implicit-GEMM convolutions, %d launches per pass)" % len(conv),
+                           "kernel": "conv_igemm_* (backbone implicit-GEMM convolutions, %d launches per pass incl. statistics-only launches)" % len(conv),
                            "avg_launch_ms": round(1e3 * tsum / len(conv), 4),
                            "alg_gflop_per_launch": round(fsum / len(conv) / 1e9, 3)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
