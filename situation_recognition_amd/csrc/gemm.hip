@@ -724,17 +724,24 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(c
 // EPI (compile time, keeps the fully unrolled epilogue small enough for the instruction cache):
 //   0 linear (+bias, +residual, optional ReLU), 2 sigmoid, 3 tanh, 4 sigmoid & r*h, 5 tanh & GRU blend  (= SR_ACT_* codes; 1 = ReLU folds into 0)
 // WAVES_N = 1: 256x64 tile, 4 waves stacked along M (each 64x64 = 4x4 fragments), 3-slot ring (60 KiB), two workgroups per CU -- N <= 64
-template <typename T, typename TO, bool CONV, int WAVES_N, int EPI>
+// CFG = 8: 256x256 tile, FOUR waves (2x2, each 128x128 = 8x8 fragments), one wave per SIMD with the whole 512-register
+//          file, 64 MFMAs per wave between barriers, 16 fragment reads per 64 MFMAs, 4-slot ring.
+template <typename T, typename TO, bool CONV, int CFG, int EPI>
 __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
-  constexpr int WAVES_M = WAVES_N == 1 ? 4 : 2, FM = 16 / WAVES_M;   // FM: 16-row fragments per wave along M
-  constexpr int BM = 256, BN = 64 * WAVES_N, NW = WAVES_M * WAVES_N;
+  constexpr int WAVES_N = CFG == 8 ? 2 : CFG, FN = CFG == 8 ? 8 : 4;   // FN: 16-column fragments per wave along N
+  constexpr int WAVES_M = CFG == 1 ? 4 : 2, FM = 16 / WAVES_M;          // FM: 16-row fragments per wave along M
+  constexpr int BM = 256, BN = 16 * FN * WAVES_N, NW = WAVES_M * WAVES_N;
   constexpr int EPC = 16 / (int)sizeof(T), BK = 4 * EPC;
-  constexpr int NSLOT = WAVES_N == 4 ? 4 : 3;
+  constexpr int NSLOT = (CFG == 4 || CFG == 8) ? 4 : 3;
+  constexpr int CPR = 2 * FN;          // 16-byte chunks per row of the per-wave output strip
+  constexpr int RPI = 64 / CPR;        // strip rows moved by one wave-instruction
+  constexpr int NH = 16 / RPI;         // instructions per 16-row strip
   constexpr int SLOT = (BM + BN) * 64, STG_OFF = NSLOT * SLOT;
   constexpr int A_PER = (BM / 16) / NW, B_PER = (BN / 16) / NW;
   constexpr int L = A_PER + B_PER;                      // DMA instructions per lane per step
   constexpr bool STAGED = sizeof(TO) == 2;              // 16-bit outputs leave through a per-wave LDS staging strip
-  constexpr int S = STAGED ? 2 * FM : 4 * FM;           // store instructions per lane per epilogue (single output)
+  constexpr int S = STAGED ? NH * FM : (FN * FM <= 32 ? FN * FM : 0);   // store instructions per lane per epilogue (0: wait for them)
+  static_assert(3 * L + S < 64, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -851,17 +858,17 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     }
   };
 
-  f32x4_t acc[4][FM];  // [n-fragment j][m-fragment i]
+  f32x4_t acc[FN][FM];  // [n-fragment j][m-fragment i]
   auto clear_acc = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int i = 0; i < FM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   };
   clear_acc();
 
   const int a_off = (wm * FM * 16 + (lane & 15)) * 64 + fsw;
-  const int b_off = BM * 64 + (wn * 64 + (lane & 15)) * 64 + fsw;
+  const int b_off = BM * 64 + (wn * FN * 16 + (lane & 15)) * 64 + fsw;
   auto rdA = [&](int slot, int i) { return *reinterpret_cast<const Frag<T>*>(smem + slot * SLOT + a_off + i * 16 * 64); };
   auto rdB = [&](int slot, int j) { return *reinterpret_cast<const Frag<T>*>(smem + slot * SLOT + b_off + j * 16 * 64); };
 
@@ -878,22 +885,22 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     const int el = fresh_lane();
     const int frow = el & 15, fgrp = el >> 4;
     TO* const trash = reinterpret_cast<TO*>((char*)p.trash_page + el * 16);
-    float bv[4][4];
+    float bv[FN][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wn * 64 + j * 16 + fgrp * 4 + r;
+        const int n = n0 + wn * FN * 16 + j * 16 + fgrp * 4 + r;
         const int nn = n < p.N ? n : p.N - 1;
         bv[j][r] = (p.bias ? p.bias_scale * p.bias[nn] : 0.f) + (p.bias2 ? p.bias2[nn] : 0.f);
       }
     const bool scaled = p.escale != nullptr;
     if (scaled) {  // fold the multiplier into the accumulators once (registers: none extra)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < FN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int n = n0 + wn * 64 + j * 16 + fgrp * 4 + r;
+          const int n = n0 + wn * FN * 16 + j * 16 + fgrp * 4 + r;
           const float e = p.escale[n < p.N ? n : p.N - 1];
 #pragma unroll
           for (int i = 0; i < FM; ++i) acc[j][i][r] *= e;
@@ -904,9 +911,9 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
       // wave's 128 rows -> its own partial row [2*tm + wm] of `stats` (no LDS, no barrier: the two wave groups run
       // half a step apart and must not meet at a barrier here)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < FN; ++j) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-        const int nj = n0 + wn * 64 + j * 16 + fgrp * 4;
+        const int nj = n0 + wn * FN * 16 + j * 16 + fgrp * 4;
         const bool nok = nj < Nv;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -934,13 +941,15 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     // whole 16-byte row chunks, coalesced, one strip ahead, and added (+ReLU) after the LDS transpose, on the output rows.
     constexpr bool ROWRES = STAGED && EPI == 0;
     const bool rowres = ROWRES && p.res != nullptr;
-    uint4 rnext[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-    auto fetch_res = [&](int i, uint4 (&dst)[2]) {
+    uint4 rnext[NH];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r16 = h * 8 + (el >> 3), c8 = (el & 7) * 8;
+    for (int h = 0; h < NH; ++h) rnext[h] = make_uint4(0, 0, 0, 0);
+    auto fetch_res = [&](int i, uint4 (&dst)[NH]) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int r16 = h * RPI + el / CPR, c8 = (el % CPR) * 8;
         const long mm = m0 + wm * FM * 16 + i * 16 + r16;
-        const int nn = n0 + wn * 64 + c8;
+        const int nn = n0 + wn * FN * 16 + c8;
         const bool okk = (mm < p.M) && (nn + 8 <= Nv);
         dst[h] = *reinterpret_cast<const uint4*>(okk ? (const char*)((const TO*)p.res + mm * p.ldres + nn) : (const char*)p.zero_page);
       }
@@ -948,13 +957,15 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     if (rowres) fetch_res(0, rnext);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      uint4 rcur[2] = {rnext[0], rnext[1]};
+      uint4 rcur[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) rcur[h] = rnext[h];
       if (rowres && i + 1 < FM) fetch_res(i + 1, rnext);
       const long m = m0 + wm * FM * 16 + i * 16 + frow;
-      char* stg = smem + STG_OFF + wave * 2048;             // per-wave [16 rows][64 cols] 16-bit strip; 16-B chunk c of row r at c ^ (r & 7)
+      char* stg = smem + STG_OFF + wave * (16 * CPR * 16);  // per-wave [16 rows][16*FN cols] 16-bit strip; 16-B chunk c of row r at c ^ (r & (CPR-1))
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + fgrp * 4;
+      for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * FN * 16 + j * 16 + fgrp * 4;
         const bool ok = (m < p.M) && (n < Nv);
         float v[4], o2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -993,7 +1004,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
           }
         }
         if (STAGED && !two) {
-          store4<TO>(reinterpret_cast<TO*>(stg + frow * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8), v);
+          store4<TO>(reinterpret_cast<TO*>(stg + frow * (CPR * 16) + (((j * 2 + (fgrp >> 1)) ^ (frow & (CPR - 1))) << 4) + (fgrp & 1) * 8), v);
         } else {
           store4<TO>(ok ? (TO*)p.C + m * p.ldc + n : trash, v);
           if (two) store4<TO>(ok ? (TO*)p.C2 + m * p.ldc + n : trash, o2);
@@ -1004,11 +1015,11 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         // 128-byte row segment) -> 2 store instructions per strip, full-line coalescing
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int r16 = h * 8 + (el >> 3), c8 = (el & 7) * 8;
+        for (int h = 0; h < NH; ++h) {
+          const int r16 = h * RPI + el / CPR, c8 = (el % CPR) * 8;
           const long mm = m0 + wm * FM * 16 + i * 16 + r16;
-          const int nn = n0 + wn * 64 + c8;
-          uint4 val = *reinterpret_cast<const uint4*>(stg + r16 * 128 + (((el & 7) ^ (r16 & 7)) << 4));
+          const int nn = n0 + wn * FN * 16 + c8;
+          uint4 val = *reinterpret_cast<const uint4*>(stg + r16 * (CPR * 16) + ((((el % CPR)) ^ (r16 & (CPR - 1))) << 4));
           if constexpr (ROWRES) {
             if (rowres) {
               const unsigned* pv_ = reinterpret_cast<const unsigned*>(&val);
@@ -1047,7 +1058,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   // at once: HBM idles during the K loops and is oversubscribed during the epilogues (measured: store phase as long
   // as the K loop on output-heavy shapes).  Starting workgroup g with a delay of (g mod 8)/8 of a tile period keeps
   // only 1/8 of the chip in its store phase at any time.  Purely a timing nudge: no correctness dependence.
-  if (WAVES_N <= 2 && my_tiles >= 4 && !(p.debug & 8)) {
+  if (CFG <= 2 && my_tiles >= 4 && !(p.debug & 8)) {
     // two workgroups share a CU (second dispatch round = upper half of the grid): offset them by half a tile period so
     // that one is in its K loop while the other drains its stores
     const unsigned long long period = (unsigned long long)nkt * 2300ull + 16000ull;   // cycles per tile, roughly
@@ -1070,12 +1081,12 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   if (issued >= 4) wait_vm<3 * L>(); else if (issued == 3) wait_vm<2 * L>(); else if (issued == 2) wait_vm<L>(); else wait_vm<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  Frag<T> a[FM], b[4], bs[2];
+  Frag<T> a[FM], b[FN], bs[2];
 #pragma unroll
   for (int i = 0; i < FM; ++i) a[i] = rdA(0, i);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) b[j] = rdB(0, j);
-  bs[0] = b[2]; bs[1] = b[3];
+  for (int j = 0; j < FN; ++j) b[j] = rdB(0, j);
+  bs[0] = b[FN - 2]; bs[1] = b[FN - 1];
 
   int c_tile = vb, c_kt = 0;
   bool stored = false;
@@ -1091,7 +1102,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   auto wait_step = [&](int k) {
     if (k >= total) return;
     const int later = issued - k - 1;  // 0..2
-    if (stored && !two) {
+    if (stored && !two && S > 0) {
       if (later >= 2) wait_vm<2 * L + S>(); else if (later == 1) wait_vm<L + S>(); else wait_vm<S>();
     } else {
       if (later >= 2) wait_vm<2 * L>(); else if (later == 1) wait_vm<L>(); else wait_vm<0>();
@@ -1120,30 +1131,33 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     // are issued in sweep 0.
     // (Specialising this block four ways on (roll, do_issue) to drop the uniform branches made hipcc spill ~200 registers
     //  and ran 20x slower; the branches stay.)
+    // FN/2 sweeps over the FM row fragments; sweep k multiplies with b[2k], b[2k+1].  Fragments are re-read for step s+1 as
+    // soon as they are dead: b[2k-2], b[2k-1] during sweep k; a[i] during the last sweep; the last B pair through spares.
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      mma<T>(b[0], a[i], acc[0][i]);
-      mma<T>(b[1], a[i], acc[1][i]);
-      if (i < L && do_issue) issue_piece(i);
-      if (roll && i == FM / 2) bs[0] = rdB(nslot, 2);
-      if (roll && i == FM / 2 + FM / 4) bs[1] = rdB(nslot, 3);
-    }
-    if (do_issue) {
+    for (int k = 0; k < FN / 2; ++k) {
 #pragma unroll
-      for (int q = FM; q < L; ++q) issue_piece(q);   // (only when a lane has more DMA pieces than row fragments)
-    }
+      for (int i = 0; i < FM; ++i) {
+        mma<T>(b[2 * k], a[i], acc[2 * k][i]);
+        mma<T>(b[2 * k + 1], a[i], acc[2 * k + 1][i]);
+        if (k == 0 && i < L && do_issue) issue_piece(i);
+        if (roll) {
+          if (k == FN / 2 - 1) {
+            a[i] = rdA(nslot, i);
+          } else {
+            if (k == FN / 2 - 2 && i == FM / 2) bs[0] = rdB(nslot, FN - 2);
+            if (k == FN / 2 - 2 && i == FM / 2 + FM / 4) bs[1] = rdB(nslot, FN - 1);
+          }
+          if (k >= 1 && i == 0) b[2 * k - 2] = rdB(nslot, 2 * k - 2);
+          if (k >= 1 && i == 1) b[2 * k - 1] = rdB(nslot, 2 * k - 1);
+        }
+      }
+      if (k == 0 && do_issue) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      mma<T>(b[2], a[i], acc[2][i]);
-      mma<T>(b[3], a[i], acc[3][i]);
-      if (roll) {
-        a[i] = rdA(nslot, i);
-        if (i == 0) b[0] = rdB(nslot, 0);
-        if (i == 1) b[1] = rdB(nslot, 1);
+        for (int q = FM; q < L; ++q) issue_piece(q);   // (only when a lane has more DMA pieces than row fragments)
       }
     }
     if (do_issue) { end_issue(); ++issued; }
-    if (roll) { b[2] = bs[0]; b[3] = bs[1]; }
+    if (roll) { b[FN - 2] = bs[0]; b[FN - 1] = bs[1]; }
     ++c_kt;
     if (stamp) { SR_STAMP(t1); tm_ += t1 - t0; t0 = t1; }
     if (tile_end) {
@@ -1156,7 +1170,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) a[i] = rdA(nslot, i);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = rdB(nslot, j);
+        for (int j = 0; j < FN; ++j) b[j] = rdB(nslot, j);
       }
       if (stamp) { SR_STAMP(t1); te += t1 - t0; }
     }
@@ -1167,10 +1181,11 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   }
 }
 
-template <typename T, typename TO, int WAVES_N, int EPI>
-__global__ __launch_bounds__(WAVES_N == 1 ? 256 : 128 * WAVES_N, 2) void gemm_nt_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, false, WAVES_N, EPI>(p); }
-template <typename T, typename TO, int WAVES_N>
-__global__ __launch_bounds__(WAVES_N == 1 ? 256 : 128 * WAVES_N, 2) void conv_igemm_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, true, WAVES_N, 0>(p); }
+constexpr int v3_threads(int CFG) { return (CFG == 1 || CFG == 8) ? 256 : 128 * CFG; }
+template <typename T, typename TO, int CFG, int EPI>
+__global__ __launch_bounds__(v3_threads(CFG), CFG == 8 ? 1 : 2) void gemm_nt_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, false, CFG, EPI>(p); }
+template <typename T, typename TO, int CFG>
+__global__ __launch_bounds__(v3_threads(CFG), CFG == 8 ? 1 : 2) void conv_igemm_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, true, CFG, 0>(p); }
 
 inline bool use_v1() {
   static const bool v1 = [] { const char* e = getenv("SR_GEMM_V1"); return e && e[0] == '1'; }();
@@ -1233,7 +1248,7 @@ inline bool use_v3() {
 
 template <typename T, typename TO, int WN, int EPI>
 int launch_v3e(const KArgs& k, unsigned grid, size_t lds, hipStream_t st) {
-  constexpr int NTHR = WN == 1 ? 256 : 128 * WN;
+  constexpr int NTHR = v3_threads(WN);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v3_kernel<T, TO, WN, EPI>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr != hipSuccess) return SR_ERR_LAUNCH;
@@ -1245,10 +1260,11 @@ template <typename T, typename TO, int WN>
 int launch_v3(const KArgs& k_in, hipStream_t st) {
   KArgs k = k_in;
   for (int i = 0; i < 3; ++i) k.nk[i] *= 2;  // host counts 128-byte K-tiles; v3 steps are 64 bytes
-  constexpr int BN = 64 * WN, NSLOT = WN == 4 ? 4 : 3, NTHR = WN == 1 ? 256 : 128 * WN, WG_PER_CU = WN == 4 ? 1 : 2;
+  constexpr int BN = WN == 8 ? 256 : 64 * WN, NSLOT = (WN == 4 || WN == 8) ? 4 : 3, NTHR = v3_threads(WN);
+  constexpr int WG_PER_CU = (WN == 4 || WN == 8) ? 1 : 2;
   const long gm = ((long)k.M + 255) / 256, gn = (k.N + BN - 1) / BN;
   if (gm * gn > 0x7fffffffL) return SR_ERR_ARG;
-  const size_t lds = NSLOT * (256 + BN) * 64 + (NTHR / 64) * 2048;
+  const size_t lds = NSLOT * (256 + BN) * 64 + (NTHR / 64) * (WN == 8 ? 4096 : 2048);
   const long ntiles = gm * gn, cap = (long)num_cus() * WG_PER_CU;
   const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
   int rc = SR_OK;
@@ -1315,6 +1331,8 @@ template <typename T, typename TO>
 int launch(const KArgs& k, hipStream_t st) {
   if (use_v1()) return k.N <= 64 ? launch_cfg<T, TO, 4, 1>(k, st) : launch_cfg<T, TO, 2, 2>(k, st);
   const bool linear = k.act == SR_ACT_NONE || k.act == SR_ACT_RELU;
+  // CFG 8 (four 128x128 waves, one per SIMD) is supported by the template but not instantiated: hipcc keeps all 64 accumulator
+  // tiles in AGPRs and spills them inside the K loop (64 scratch reloads per step, 10x slower than CFG 4).
   if (k.N > 128 && use_v3() && !(linear && prefer_narrow(k))) return launch_v3<T, TO, 4>(k, st);
   if (k.N > 64 && use_v3() && linear) return launch_v3<T, TO, 2>(k, st);
   if (k.N <= 64 && use_v3() && linear && !no_v3_n64()) return launch_v3<T, TO, 1>(k, st);
