@@ -134,6 +134,8 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if os.environ.get("SR_FORCE_DEVICE"):        # rehearsal of the N>1 path on a one-GPU box (with SR_DIST_BACKEND=gloo)
+        local = int(os.environ["SR_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ops.lib()
