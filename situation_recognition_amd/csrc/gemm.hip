@@ -1133,6 +1133,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     //  and ran 20x slower; the branches stay.)
     // FN/2 sweeps over the FM row fragments; sweep k multiplies with b[2k], b[2k+1].  Fragments are re-read for step s+1 as
     // soon as they are dead: b[2k-2], b[2k-1] during sweep k; a[i] during the last sweep; the last B pair through spares.
+    if (p.debug & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int k = 0; k < FN / 2; ++k) {
 #pragma unroll
@@ -1156,6 +1157,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         for (int q = FM; q < L; ++q) issue_piece(q);   // (only when a lane has more DMA pieces than row fragments)
       }
     }
+    if (p.debug & 16) __builtin_amdgcn_s_setprio(0);
     if (do_issue) { end_issue(); ++issued; }
     if (roll) { b[FN - 2] = bs[0]; b[FN - 1] = bs[1]; }
     ++c_kt;
