@@ -2,24 +2,17 @@
 //
 //   C[M,N] = epilogue( sum_p A_p[M,K_p] . W_p[N,K_p]^T )
 //
-// One kernel serves nn.Linear-shaped GEMMs (GGNN gates, classifiers, their backward
-// GEMMs) and NHWC convolutions (the A rows are gathered on the fly: row m is output
-// pixel (b,ho,wo), K runs over (tap, channel)).
+// One kernel family serves nn.Linear-shaped GEMMs (GGNN gates, classifiers, their backward GEMMs) and NHWC convolutions
+// (the A rows are gathered on the fly: row m is output pixel (b,ho,wo), K runs over (tap, channel)).
 //
-// Structure (cdna_hip_programming.md 5, "minimum 2-phase" loop):
-//   * block tile (64*WAVES_M) x (64*WAVES_N), each wave owns a 64x64 output tile
-//     = 4x4 fragments of v_mfma_f32_16x16x32_bf16 (or 16x16x4_f32 for fp32 storage);
-//   * K-tile = 128 bytes per row (64 bf16 / 32 f32); both operands are staged
-//     global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB = 8 rows x 128 B per
-//     wave-instruction), double-buffered;
-//   * the LDS image is kept lane-linear for the DMA; the bank-conflict swizzle
-//     (16-B chunk c of row r lives at chunk position c ^ (r & 7)) is applied to the
-//     per-lane SOURCE address and again on the fragment ds_read_b128 (rule 21);
-//   * MFMA roles are swapped (weights = MFMA "A", activations = MFMA "B") so each lane
-//     ends up with 4 CONSECUTIVE output columns of one output row -> 8/16-byte stores;
-//   * convolution padding and row tails read from a zero page instead of branching;
-//   * workgroup -> tile mapping is XCD-aware (each XCD walks a contiguous range of row
-//     tiles so the activation panel is reused out of its own L2).
+//   v3 (default): persistent workgroups, 64-byte K-steps through a 3/4-slot LDS ring filled by LDS-DMA, counted vmcnt,
+//                 rolling fragment prefetch, LDS-staged coalesced bf16 epilogue.  Tiles 256x256 / 256x128 / 256x64.
+//   v2 (fallback for N <= 128 with a non-linear epilogue, and SR_GEMM_NO_V3=1): 128-byte K-steps, 3-slot ring, 64x64 per wave.
+//
+// Common to both: MFMA roles are swapped (weights = MFMA "A", activations = MFMA "B") so each lane ends up with 4 CONSECUTIVE
+// output columns of one output row; the LDS image is lane-linear for the DMA and the bank-conflict swizzle is applied on the
+// per-lane SOURCE address and again on the fragment ds_read_b128 (cdna_hip_programming.md rule 21); convolution padding and
+// row tails read a zero page instead of branching; the workgroup -> tile mapping is XCD-contiguous.
 #include <stdlib.h>
 
 #include "common.h"
@@ -86,287 +79,6 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
   bf16_t t[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
   *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(t);
 }
-
-// CONV selects the implicit-GEMM row gather; it is a separate kernel symbol (conv_igemm_kernel vs
-// gemm_nt_kernel in profiles) so the backbone convolutions can be told apart from the head's GEMMs.
-template <typename T, typename TO, int WAVES_M, int WAVES_N, bool CONV>
-__device__ __forceinline__ void gemm_body(const KArgs& p) {
-  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64, NW = WAVES_M * WAVES_N;
-  constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
-  constexpr int BK = 8 * EPC;               // elements per K-tile (128 B)
-  constexpr int A_PER_WAVE = (BM / 8) / NW, B_PER_WAVE = (BN / 8) / NW;
-  constexpr int STAGE = (BM + BN) * 128;
-  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide over waves");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-  // ---- XCD-aware tile mapping (bijective form, cdna_hip_programming.md 5) ----
-  const int gn = (p.N + BN - 1) / BN;
-  const int ntiles = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = ntiles >> 3, r = ntiles & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tile_m = bid / gn, tile_n = bid - tile_m * gn;
-  const long m0 = (long)tile_m * BM;
-  const int n0 = tile_n * BN;
-
-  // ---- per-lane loader geometry ----
-  const int lrow = lane >> 3;                 // row inside a 1-KiB piece
-  const int csrc = (lane & 7) ^ lrow;         // source chunk that lands at chunk position lane&7
-  const int ecol = csrc * EPC;                // element offset of that chunk in the K-tile
-
-  long a_row[A_PER_WAVE];      // plain: clamped row index; conv: element offset of x[b, ho*s-p, wo*s-p, 0]
-  unsigned a_mask[A_PER_WAVE]; // conv: bit t set <=> tap t is inside the image
-#pragma unroll
-  for (int i = 0; i < A_PER_WAVE; ++i) {
-    long m = m0 + (wave + i * NW) * 8 + lrow;
-    if (!CONV) {
-      a_row[i] = m < p.M ? m : (long)p.M - 1;
-      a_mask[i] = 0xffffffffu;
-    } else if (m >= p.M) {
-      a_row[i] = 0;
-      a_mask[i] = 0;
-    } else {
-      const unsigned hw = (unsigned)(p.cv.Ho * p.cv.Wo), um = (unsigned)m;
-      const long b = um / hw;
-      const int rem = (int)(um - (unsigned)b * hw);
-      const int ho = rem / p.cv.Wo, wo = rem - ho * p.cv.Wo;
-      const int hi0 = ho * p.cv.stride - p.cv.pad, wi0 = wo * p.cv.stride - p.cv.pad;
-      a_row[i] = ((b * p.cv.H + hi0) * (long)p.cv.Wd + wi0) * p.cv.cpix;
-      const int ntap = p.kp[0].K >> p.cv.lgCseg;
-      unsigned mk = 0;
-      for (int t = 0; t < ntap; ++t) {
-        const int dh = p.cv.KW == 1 ? t : (t * 11) >> 5, dw = t - dh * p.cv.KW;  // KW in {1,3}
-        const int hi = hi0 + dh, wi = wi0 + dw;
-        if (hi >= 0 && hi < p.cv.H && wi >= 0 && wi < p.cv.Wd) mk |= 1u << t;
-      }
-      a_mask[i] = mk;
-    }
-  }
-  int w_row[B_PER_WAVE];
-#pragma unroll
-  for (int i = 0; i < B_PER_WAVE; ++i) {
-    int n = n0 + (wave + i * NW) * 8 + lrow;
-    w_row[i] = n < p.N ? n : p.N - 1;
-  }
-
-  auto stage = [&](int buf, int kt) {
-    int pr = 0, kl = kt;
-    if (p.npairs > 1 && kl >= p.nk[0]) { kl -= p.nk[0]; pr = 1; }
-    if (p.npairs > 2 && pr == 1 && kl >= p.nk[1]) { kl -= p.nk[1]; pr = 2; }
-    const sr_kpair& kp = p.kp[pr];
-    const int k = kl * BK + ecol;
-    char* sA = smem + buf * STAGE;
-    char* sB = sA + BM * 128;
-    long tapoff = 0;
-    int tap = 0;
-    if (CONV) {
-      tap = k >> p.cv.lgCseg;
-      const int cc = k & ((1 << p.cv.lgCseg) - 1);
-      const int dh = p.cv.KW == 1 ? tap : (tap * 11) >> 5, dw = tap - dh * p.cv.KW;
-      tapoff = ((long)dh * p.cv.Wd + dw) * p.cv.cpix + cc;
-    }
-#pragma unroll
-    for (int i = 0; i < A_PER_WAVE; ++i) {
-      const T* src;
-      if (!CONV) {
-        src = (const T*)kp.A + a_row[i] * kp.lda + k;
-      } else {
-        src = ((a_mask[i] >> tap) & 1) ? (const T*)kp.A + a_row[i] + tapoff : (const T*)g_zero_page;
-      }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sA + (wave + i * NW) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER_WAVE; ++i) {
-      const T* src = (const T*)kp.W + (long)w_row[i] * kp.ldw + k;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sB + (wave + i * NW) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x4_t acc[4][4];  // [n-fragment j][m-fragment i]
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fgrp = lane >> 4;
-  auto compute = [&](int buf) {
-    const char* sA = smem + buf * STAGE + (wm * 64 + frow) * 128;
-    const char* sB = smem + buf * STAGE + BM * 128 + (wn * 64 + frow) * 128;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int sw = ((ks * 4 + fgrp) ^ (lane & 7)) << 4;
-      Frag<T> a[4], w[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const Frag<T>*>(sA + i * 16 * 128 + sw);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const Frag<T>*>(sB + j * 16 * 128 + sw);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mma<T>(w[j], a[i], acc[j][i]);
-    }
-  };
-
-  int nkt = p.nk[0];
-  if (p.npairs > 1) nkt += p.nk[1];
-  if (p.npairs > 2) nkt += p.nk[2];
-
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nkt - 1; ++kt) {
-    stage(cur ^ 1, kt + 1);
-    compute(cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
-  }
-  compute(cur);
-
-  // ---- epilogue: lane holds rows m = .. + i*16 + frow, columns n = .. + j*16 + fgrp*4 + {0..3}
-  const bool want_stats = p.stats != nullptr;
-  float s1[4][4], s2[4][4];
-  if (want_stats) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s1[j][r] = s2[j][r] = 0.f;
-  }
-  TO* C = (TO*)p.C;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wn * 64 + j * 16 + fgrp * 4;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (n + r < p.N) {
-        if (p.bias) bv[r] = p.bias_scale * p.bias[n + r];
-        if (p.bias2) bv[r] += p.bias2[n + r];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long m = m0 + wm * 64 + i * 16 + frow;
-      if (m >= p.M || n >= p.N) continue;
-      const bool full = (n + 3 < p.N);
-      float v[4], o2[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] + bv[r];
-      if (want_stats) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
-      }
-      if (p.res) {
-        const TO* rp = (const TO*)p.res + m * p.ldres + n;
-        float rv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (full) load4<TO>(rp, rv);
-        else
-          for (int r = 0; r < 4 && n + r < p.N; ++r) rv[r] = to_f<TO>(rp[r]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += rv[r];
-      }
-      bool two = false;
-      switch (p.act) {
-        case SR_ACT_RELU:
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-          break;
-        case SR_ACT_SIGMOID:
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]);
-          break;
-        case SR_ACT_TANH:
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = tanhf_(v[r]);
-          break;
-        case SR_ACT_SIGMOID_MUL: {
-          float h[4] = {0.f, 0.f, 0.f, 0.f};
-          const TO* hp = (const TO*)p.aux1 + m * p.ldc + n;
-          if (full) load4<TO>(hp, h);
-          else
-            for (int r = 0; r < 4 && n + r < p.N; ++r) h[r] = to_f<TO>(hp[r]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { v[r] = sigmoidf_(v[r]); o2[r] = v[r] * h[r]; }
-          two = true;
-        } break;
-        case SR_ACT_TANH_BLEND: {
-          float h[4] = {0.f, 0.f, 0.f, 0.f}, z[4] = {0.f, 0.f, 0.f, 0.f};
-          const TO* hp = (const TO*)p.aux1 + m * p.ldc + n;
-          const TO* zp = (const TO*)p.aux2 + m * p.ldc + n;
-          if (full) { load4<TO>(hp, h); load4<TO>(zp, z); }
-          else
-            for (int r = 0; r < 4 && n + r < p.N; ++r) { h[r] = to_f<TO>(hp[r]); z[r] = to_f<TO>(zp[r]); }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float c = tanhf_(v[r]);
-            o2[r] = c;
-            v[r] = (1.f - z[r]) * h[r] + z[r] * c;
-          }
-          two = true;
-        } break;
-        default: break;
-      }
-      TO* cp = C + m * p.ldc + n;
-      if (full) {
-        store4<TO>(cp, v);
-        if (two) store4<TO>((TO*)p.C2 + m * p.ldc + n, o2);
-      } else {
-        for (int r = 0; r < 4 && n + r < p.N; ++r) {
-          cp[r] = from_f<TO>(v[r]);
-          if (two) ((TO*)p.C2)[m * p.ldc + n + r] = from_f<TO>(o2[r]);
-        }
-      }
-    }
-  }
-
-  if (want_stats) {
-    // columns are shared by the 16 lanes of a lane group and by the WAVES_M waves of a wave column
-    float* red = reinterpret_cast<float*>(smem);  // [2][WAVES_M][BN]
-    __syncthreads();                              // staging buffers are dead from here on
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = s1[j][r], b = s2[j][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        if (frow == 0) {
-          const int col = wn * 64 + j * 16 + fgrp * 4 + r;
-          red[(0 * WAVES_M + wm) * BN + col] = a;
-          red[(1 * WAVES_M + wm) * BN + col] = b;
-        }
-      }
-    __syncthreads();
-    for (int t = threadIdx.x; t < 2 * BN; t += NW * 64) {
-      const int which = t / BN, col = t - which * BN;
-      if (n0 + col < p.N) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES_M; ++w) s += red[(which * WAVES_M + w) * BN + col];
-        p.stats[((long)tile_m * 2 + which) * p.N + n0 + col] = s;
-      }
-    }
-  }
-}
-
-template <typename T, typename TO, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_nt_kernel(const KArgs p) {
-  gemm_body<T, TO, WAVES_M, WAVES_N, false>(p);
-}
-template <typename T, typename TO, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(const KArgs p) {
-  gemm_body<T, TO, WAVES_M, WAVES_N, true>(p);
-}
-
 
 // =====================================================================================================
 // v2: persistent workgroups + 3-stage LDS-DMA ring (default).
@@ -1189,10 +901,6 @@ __global__ __launch_bounds__(v3_threads(CFG), CFG == 8 ? 1 : 2) void gemm_nt_v3_
 template <typename T, typename TO, int CFG>
 __global__ __launch_bounds__(v3_threads(CFG), CFG == 8 ? 1 : 2) void conv_igemm_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, true, CFG, 0>(p); }
 
-inline bool use_v1() {
-  static const bool v1 = [] { const char* e = getenv("SR_GEMM_V1"); return e && e[0] == '1'; }();
-  return v1;
-}
 inline int num_cus() {
   static const int n = [] {
     int dev = 0, cu = 256;
@@ -1245,7 +953,7 @@ inline bool no_v3_n64() {
 }
 inline bool use_v3() {
   static const bool off = [] { const char* e = getenv("SR_GEMM_NO_V3"); return e && e[0] == '1'; }();
-  return !off && !use_v1();
+  return !off;
 }
 
 template <typename T, typename TO, int WN, int EPI>
@@ -1291,53 +999,43 @@ int launch_v3(const KArgs& k_in, hipStream_t st) {
   return SR_OK;
 }
 
-// 256x128 / two workgroups per CU when the tile's K loop is short relative to its epilogue (output-heavy)
-inline bool prefer_narrow(const KArgs& k) {
+// Which v3 tile shape serves (M, N)?  4: 256x256 (8 waves), 2: 256x128, 1: 256x64 (both 4 waves, two workgroups per CU), 0: not v3.
+// Only linear epilogues have the narrow shapes.  sr_gemm_stats_tiles() must agree with this, so it depends on M and N alone.
+inline int v3_cfg(long M, int N, bool linear) {
+  if (!use_v3()) return 0;
   static const int force = [] { const char* e = getenv("SR_GEMM_NARROW"); return e ? atoi(e) : -1; }();
-  if (force > 0) return true;
-  // Wave quantisation: with few tiles per CU the last round of 256x256 tiles leaves most CUs idle (e.g. 294 tiles on 256 CUs
-  // = 57 % busy).  256x128 tiles run two workgroups per CU (512 slots) and halve the granule; take them when that fills
-  // the chip noticeably better.  (On long, output-heavy launches the two shapes measured within 3 % of each other.)
   const long cus = num_cus();
-  const long tw = (((long)k.M + 255) / 256) * ((k.N + 255) / 256), tn = (((long)k.M + 255) / 256) * ((k.N + 127) / 128);
-  if (tw >= 6 * cus) return false;
-  const double ew = (double)tw / (double)(((tw + cus - 1) / cus) * cus);
-  const double en = (double)tn / (double)(((tn + 2 * cus - 1) / (2 * cus)) * (2 * cus));
-  return en > ew + 0.08;
-}
-
-inline int tile_m_for(int N) { return use_v1() ? (N <= 64 ? 256 : 128) : 256; }
-
-template <typename T, typename TO, int WM, int WN>
-int launch_cfg(const KArgs& k, hipStream_t st) {
-  constexpr int BM = WM * 64, BN = WN * 64;
-  const long gm = ((long)k.M + BM - 1) / BM, gn = (k.N + BN - 1) / BN;
-  if (gm * gn > 0x7fffffffL) return SR_ERR_ARG;
-  const size_t lds = 2 * (BM + BN) * 128;
-  if (k.cv.on) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, TO, WM, WN>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return SR_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, TO, WM, WN>), dim3((unsigned)(gm * gn)), dim3(WM * WN * 64), lds, st, k);
-  } else {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return SR_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN>), dim3((unsigned)(gm * gn)), dim3(WM * WN * 64), lds, st, k);
+  const long gm = (M + 255) / 256;
+  if (linear) {
+    if (N <= 64) return no_v3_n64() ? 0 : 1;
+    if (N <= 128 || force > 0) return 2;
+    // Few tiles (small batch, single-image inference): a 256x256 tile would leave most CUs idle and run its whole K loop on
+    // one of them; narrower tiles multiply the workgroups.
+    const long tw = gm * ((N + 255) / 256);
+    if (tw * 8 <= cus) return 1;
+    if (tw * 4 <= cus) return 2;
+    // Wave quantisation at medium sizes: two workgroups per CU (512 slots) halve the granule.
+    if (tw < 6 * cus) {
+      const long tn = gm * ((N + 127) / 128);
+      const double ew = (double)tw / (double)(((tw + cus - 1) / cus) * cus);
+      const double en = (double)tn / (double)(((tn + 2 * cus - 1) / (2 * cus)) * (2 * cus));
+      if (en > ew + 0.08) return 2;
+    }
+    return 4;
   }
-  SR_CHECK_LAUNCH();
-  return SR_OK;
+  return N > 128 ? 4 : 0;
 }
+
 
 template <typename T, typename TO>
 int launch(const KArgs& k, hipStream_t st) {
-  if (use_v1()) return k.N <= 64 ? launch_cfg<T, TO, 4, 1>(k, st) : launch_cfg<T, TO, 2, 2>(k, st);
   const bool linear = k.act == SR_ACT_NONE || k.act == SR_ACT_RELU;
-  // CFG 8 (four 128x128 waves, one per SIMD) is supported by the template but not instantiated: hipcc keeps all 64 accumulator
-  // tiles in AGPRs and spills them inside the K loop (64 scratch reloads per step, 10x slower than CFG 4).
-  if (k.N > 128 && use_v3() && !(linear && prefer_narrow(k))) return launch_v3<T, TO, 4>(k, st);
-  if (k.N > 64 && use_v3() && linear) return launch_v3<T, TO, 2>(k, st);
-  if (k.N <= 64 && use_v3() && linear && !no_v3_n64()) return launch_v3<T, TO, 1>(k, st);
+  switch (v3_cfg(k.M, k.N, linear)) {
+    case 4: return launch_v3<T, TO, 4>(k, st);
+    case 2: return launch_v3<T, TO, 2>(k, st);
+    case 1: return launch_v3<T, TO, 1>(k, st);
+    default: break;
+  }
   return k.N <= 64 ? launch_v2<T, TO, 4, 1>(k, st) : launch_v2<T, TO, 4, 2>(k, st);
 }
 
@@ -1380,10 +1078,12 @@ extern "C" int sr_debug_stamps(unsigned long long* host_out, int count) {
 }
 
 extern "C" int sr_gemm_stats_tiles(int M, int N) {
-  if (!use_v1() && N > 64 && use_v3()) return 2 * ((M + 255) / 256);  // v3: one partial row per 128-row wave group
-  if (!use_v1() && N <= 64 && use_v3() && !no_v3_n64()) return 4 * ((M + 255) / 256);  // 256x64 tiles: four 64-row wave groups
-  const int bm = tile_m_for(N);
-  return (M + bm - 1) / bm;
+  const int gm = (M + 255) / 256;
+  switch (v3_cfg(M, N, true)) {          // statistics are only produced with a linear epilogue
+    case 4: case 2: return 2 * gm;       // one partial row per 128-row wave group
+    case 1: return 4 * gm;               // four 64-row wave groups per tile
+    default: return gm;                  // v2: one row per 256-row tile
+  }
 }
 
 extern "C" int sr_gemm(const sr_gemm_args* a, int dtype, void* stream) {

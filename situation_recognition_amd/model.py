@@ -188,6 +188,8 @@ class resnet(nn.Module):
         self.depth = depth
         self._units = None
         self.two_pass = True           # train-mode BN of output-heavy 1x1 convs in two conv launches (see _unit)
+        self.use_graphs = False        # eval-mode passes replayed from a captured hipGraph (opt-in: FCGGNN.enable_graphs())
+        self._graphs = {}
         self._stats_epoch = 0          # bumped whenever a train-mode pass changed running statistics
         self._pending_tracked = 0      # num_batches_tracked increments not yet written to the buffers
         self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_counters())
@@ -247,6 +249,32 @@ class resnet(nn.Module):
     def forward(self, x, bn_updates=1):
         """`bn_updates`=2 gives the running-statistics state of two consecutive train-mode passes over the
         same batch in one pass (FCGGNN.forward runs convnet_nouns twice on the same images, model.py:176-178)."""
+        if self.use_graphs and not self.training and x.is_cuda:
+            return self._graph_forward(x)
+        return self._forward_impl(x, bn_updates)
+
+    # -- eval-mode pass replayed from a hipGraph (single-image inference is launch-bound: ~320 kernel launches of a few
+    #    microseconds each; one graph launch replaces them)
+    def _graph_forward(self, x):
+        w = self.model.conv1.weight
+        key = (tuple(x.shape), self.dtype, w.data_ptr(), w._version, self._stats_epoch)
+        hit = self._graphs.get(key)
+        if hit is None:
+            self._forward_impl(x, 1)                        # eager warm-up: builds the folded packs, sets kernel attributes
+            torch.cuda.synchronize()
+            static_in = x.detach().float().contiguous().clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = self._forward_impl(static_in, 1)
+            if len(self._graphs) >= 4:
+                self._graphs.pop(next(iter(self._graphs)))
+            hit = self._graphs[key] = (g, static_in, static_out)
+        g, static_in, static_out = hit
+        static_in.copy_(x)
+        g.replay()
+        return static_out.clone()
+
+    def _forward_impl(self, x, bn_updates=1):
         if not x.is_cuda:
             raise SrError("situation_recognition_amd.resnet runs on an MI355X only (got a CPU tensor; no CPU fallback)")
         if x.dim() != 4 or x.shape[1] != 3:
@@ -498,6 +526,11 @@ class FCGGNN(nn.Module):
         self._drop_counter = 0
         self.drop_seed_base = 0x5eed
         self._noun_feat_cache = None
+
+    def enable_graphs(self, on=True):
+        """Replay the eval-mode backbone passes from captured hipGraphs (latency path for single-image inference)."""
+        self.convnet_verbs.use_graphs = self.convnet_nouns.use_graphs = on
+        return self
 
     # -- helpers
     def _drop_seed(self, p):

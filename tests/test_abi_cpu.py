@@ -36,10 +36,13 @@ def test_argument_validation_needs_no_gpu(libpath):
     a.npairs, a.M, a.N = 1, 4, 4
     assert l.sr_gemm(ctypes.byref(a), 7, None) in (-1, -2)
     assert l.sr_conv2d(None, 1, None) == -1
-    assert l.sr_gemm_stats_tiles(1000, 64) == 16                  # 256x64 tiles of four 64-row wave groups
-    assert l.sr_gemm_stats_tiles(1000, 256) == 8                  # 256-row tiles of 128-row wave groups: one row each
+    # partial-statistics rows follow the tile shape the kernel will pick for (M, N): 256x64 tiles -> 4 rows per 256 rows,
+    # 256x128 / 256x256 -> 2; small problems are given the narrow shapes so that more workgroups exist
+    assert l.sr_gemm_stats_tiles(1000, 64) == 16
     assert l.sr_gemm_stats_tiles(1000, 128) == 8
-
+    assert l.sr_gemm_stats_tiles(1000, 256) == 16
+    assert l.sr_gemm_stats_tiles(1204224, 256) == 2 * 4704
+    assert l.sr_gemm_stats_tiles(1204224, 64) == 4 * 4704
 
 def test_no_cpu_fallback():
     from situation_recognition_amd._lib import SrError
