@@ -235,6 +235,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
+        parallel.barrier()                      # rank 0 may still be in its roofline leg
         torch.distributed.destroy_process_group()
 
 
