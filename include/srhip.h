@@ -104,6 +104,14 @@ int sr_conv2d(const sr_conv_args* a, int dtype, void* stream);
  * in `dtype`; replaces the layout work cuDNN does for the 7x7 stem (model.py:35). */
 int sr_stem_prep(const float* img, void* out, int B, int H, int W, int dtype, void* stream);
 
+/* uint8 input pipeline: decoded NHWC images [B,H0,W0,3] (device) -> the stem's padded NHWC4 input of an HxW crop, normalised
+ * with mean3/std3 (HOST pointers, 3 floats each), per-image crop origin crop_yx int32 [B][2] (device, NULL = no crop, needs
+ * H0==H, W0==W) and per-image horizontal flip flags uint8 [B] (device, NULL = none).  Fuses the reference's
+ * RandomCrop/CenterCrop + RandomHorizontalFlip + ToTensor + Normalize (imsitu_encoder.py:21-36) with sr_stem_prep, so the
+ * 3.7 GB fp32 NCHW batch never exists. */
+int sr_image_prep_u8(const uint8_t* img, void* out, int B, int H0, int W0, int H, int W, const int32_t* crop_yx,
+                     const uint8_t* flip, const float* mean3, const float* std3, int dtype, void* stream);
+
 /* Train-mode BatchNorm, phase 2 (reference: model.train() at sr.py:16 puts the frozen
  * backbone's BatchNorm2d in batch-statistics mode).  Reduces the per-tile partials written by
  * sr_conv2d, produces scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, and applies the

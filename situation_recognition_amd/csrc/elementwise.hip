@@ -40,6 +40,40 @@ __global__ void stem_prep_kernel(const float* __restrict__ img, T* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ uint8 input pipeline
+// in: uint8 NHWC [B,H0,W0,3] (decoded, resized images); out: T [B,Hp,Wp,4] = the stem's padded NHWC4 input of an HxW crop:
+// out[b,3+h,3+w,c] = (in[b, y0_b+h, x0_b+(flip_b ? W-1-w : w), c]/255 - mean[c]) / std[c]; zero border / 4th channel.
+// Fuses RandomCrop/CenterCrop + RandomHorizontalFlip + ToTensor + Normalize (reference imsitu_encoder.py:21-36) with sr_stem_prep.
+template <typename T>
+__global__ void image_prep_u8_kernel(const uint8_t* __restrict__ img, T* __restrict__ out, int B, int H0, int W0, int H, int W,
+                                     int Hp, int Wp, const int32_t* __restrict__ crop, const uint8_t* __restrict__ flip,
+                                     float m0, float m1, float m2, float i0, float i1, float i2) {
+  const long total = (long)B * Hp * Wp;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int wp = (int)(idx % Wp);
+    const long t = idx / Wp;
+    const int hp = (int)(t % Hp);
+    const long b = t / Hp;
+    const int h = hp - 3, w = wp - 3;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (h >= 0 && h < H && w >= 0 && w < W) {
+      const int y = (crop ? crop[2 * b] : 0) + h;
+      const int x = (crop ? crop[2 * b + 1] : 0) + ((flip && flip[b]) ? W - 1 - w : w);
+      const uint8_t* src = img + ((b * H0 + y) * (long)W0 + x) * 3;
+      v[0] = ((float)src[0] * (1.f / 255.f) - m0) * i0;
+      v[1] = ((float)src[1] * (1.f / 255.f) - m1) * i1;
+      v[2] = ((float)src[2] * (1.f / 255.f) - m2) * i2;
+    }
+    T* dst = out + idx * 4;
+    if constexpr (sizeof(T) == 2) {
+      bf16_t tmp[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)0.f};
+      *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(tmp);
+    } else {
+      *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], 0.f);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ BN finalize
 // Stage A: grid (C/64, chunks): each workgroup folds its slice of the per-tile partial sums into one
 // fp64 partial per channel (deterministic order).  Stage B: one thread per channel folds the <= 256 chunk partials.
@@ -284,6 +318,21 @@ extern "C" int sr_stem_prep(const float* img, void* out, int B, int H, int W, in
   const long total = (long)B * Hp * Wp;
   DT_SWITCH(dtype, hipLaunchKernelGGL(stem_prep_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                                       img, (T*)out, B, H, W, Hp, Wp));
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int sr_image_prep_u8(const uint8_t* img, void* out, int B, int H0, int W0, int H, int W, const int32_t* crop_yx,
+                                const uint8_t* flip, const float* mean3, const float* std3, int dtype, void* stream) {
+  if (!img || !out || !mean3 || !std3 || B <= 0 || H <= 0 || W <= 0 || H0 < H || W0 < W) return SR_ERR_ARG;
+  if (!crop_yx && (H0 != H || W0 != W)) return SR_ERR_ARG;
+  for (int c = 0; c < 3; ++c)
+    if (!(std3[c] > 0.f)) return SR_ERR_ARG;
+  const int Hp = (H + 6 + 1) & ~1, Wp = (W + 6 + 1) & ~1;
+  const long total = (long)B * Hp * Wp;
+  DT_SWITCH(dtype, hipLaunchKernelGGL(image_prep_u8_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, img,
+                                      (T*)out, B, H0, W0, H, W, Hp, Wp, crop_yx, flip, mean3[0], mean3[1], mean3[2],
+                                      1.f / std3[0], 1.f / std3[1], 1.f / std3[2]));
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

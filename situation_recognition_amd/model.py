@@ -262,7 +262,7 @@ class resnet(nn.Module):
         if hit is None:
             self._forward_impl(x, 1)                        # eager warm-up: builds the folded packs, sets kernel attributes
             torch.cuda.synchronize()
-            static_in = x.detach().float().contiguous().clone()
+            static_in = (x if x.dtype == torch.uint8 else x.detach().float()).contiguous().clone()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 static_out = self._forward_impl(static_in, 1)
@@ -277,16 +277,21 @@ class resnet(nn.Module):
     def _forward_impl(self, x, bn_updates=1):
         if not x.is_cuda:
             raise SrError("situation_recognition_amd.resnet runs on an MI355X only (got a CPU tensor; no CPU fallback)")
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise SrError("expected an image batch [B,3,H,W]")
+        u8 = x.dtype == torch.uint8
+        if x.dim() != 4 or (x.shape[3] if u8 else x.shape[1]) != 3:
+            raise SrError("expected an image batch: fp32 [B,3,H,W] (reference layout) or decoded uint8 [B,H,W,3]")
         stem, blocks = self._plan()
         train = self.training
         bn0 = self.model.bn1
         m = bn0.momentum if bn0.momentum is not None else 0.1
         momentum = 1.0 - (1.0 - m) ** bn_updates
         with torch.no_grad():
-            H, W = x.shape[2], x.shape[3]
-            xp = ops.stem_prep(x.float().contiguous(), self.dtype)
+            if u8:      # decoded images: ToTensor + Normalize fused into the stem's layout kernel (no fp32 batch)
+                H, W = x.shape[1], x.shape[2]
+                xp = ops.image_prep_u8(x.contiguous(), self.dtype)
+            else:
+                H, W = x.shape[2], x.shape[3]
+                xp = ops.stem_prep(x.float().contiguous(), self.dtype)
             a = self._unit(xp, stem, train, momentum, relu=True, stem_hw=(H, W), pool_after=True)
             for convs, ds in blocks:
                 idn = a if ds is None else self._unit(a, ds, train, momentum, relu=False)

@@ -127,6 +127,27 @@ def stem_prep(img, dtype):
 _BN_SCRATCH = {}
 
 
+_MEAN3 = (C.c_float * 3)(0.485, 0.456, 0.406)
+_STD3 = (C.c_float * 3)(0.229, 0.224, 0.225)
+
+
+def image_prep_u8(img_u8, dtype, out_hw=None, crop_yx=None, flip=None):
+    """uint8 NHWC [B,H0,W0,3] -> padded NHWC4 stem input of an HxW crop, ImageNet-normalised (see sr_image_prep_u8)."""
+    require_gpu(img_u8, crop_yx, flip)
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 4 or img_u8.shape[3] != 3:
+        raise L.SrError("image_prep_u8 expects uint8 [B,H,W,3]")
+    B, H0, W0, _ = img_u8.shape
+    H, W_ = out_hw if out_hw is not None else (H0, W0)
+    if crop_yx is not None and (crop_yx.dtype != torch.int32 or tuple(crop_yx.shape) != (B, 2)):
+        raise L.SrError("crop_yx must be int32 [B,2]")
+    if flip is not None and (flip.dtype != torch.uint8 or tuple(flip.shape) != (B,)):
+        raise L.SrError("flip must be uint8 [B]")
+    out = torch.empty((B, (H + 7) & ~1, (W_ + 7) & ~1, 4), device=img_u8.device, dtype=dtype)
+    check(lib().sr_image_prep_u8(img_u8.data_ptr(), out.data_ptr(), B, H0, W0, H, W_, ptr(crop_yx), ptr(flip), _MEAN3, _STD3,
+                                 dtype_code(dtype), stream()), "sr_image_prep_u8")
+    return out
+
+
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps):
     require_gpu(stats, gamma, beta, running_mean, running_var)
     Cc = stats.shape[2]

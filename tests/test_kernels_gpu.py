@@ -261,3 +261,30 @@ def test_transpose_colsum_cast_dropout(ops, dtype):
     assert torch.equal(y.cpu().float(), xx.float() * 2 * m.cpu().float())
     assert 0.48 < float(m.float().mean()) < 0.52
     assert not torch.equal(m, ops.dropout_half(xx.cuda(), 99, want_mask=True)[1])
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_image_prep_u8_matches_totensor_normalize_crop_flip(ops, dtype):
+    """uint8 NHWC -> padded NHWC4: must equal crop + flip + ToTensor + Normalize (reference imsitu_encoder.py:21-36) followed
+    by the fp32 stem_prep path."""
+    g = torch.Generator().manual_seed(0)
+    B, H0, W0, H, W = 3, 40, 52, 32, 36
+    img = torch.randint(0, 256, (B, H0, W0, 3), generator=g, dtype=torch.uint8)
+    crop = torch.tensor([[0, 0], [8, 16], [5, 3]], dtype=torch.int32)
+    flip = torch.tensor([0, 1, 1], dtype=torch.uint8)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    ref = []
+    for b in range(B):
+        y0, x0 = int(crop[b, 0]), int(crop[b, 1])
+        c = img[b, y0:y0 + H, x0:x0 + W].float() / 255.0
+        if flip[b]:
+            c = c.flip(1)
+        ref.append(((c - mean) / std).permute(2, 0, 1))
+    ref = torch.stack(ref)                                              # [B,3,H,W] fp32, what the DataLoader would deliver
+    want = ops.stem_prep(ref.cuda(), dtype)
+    got = ops.image_prep_u8(img.cuda(), dtype, out_hw=(H, W), crop_yx=crop.cuda(), flip=flip.cuda())
+    assert got.shape == want.shape
+    assert float((got.float() - want.float()).abs().max()) <= (1e-6 if dtype == torch.float32 else 2e-2)
+    full = ops.image_prep_u8(img.cuda(), dtype)                         # no crop / flip
+    want2 = ops.stem_prep(((img.float() / 255.0 - mean) / std).permute(0, 3, 1, 2).contiguous().cuda(), dtype)
+    assert float((full.float() - want2.float()).abs().max()) <= (1e-6 if dtype == torch.float32 else 2e-2)

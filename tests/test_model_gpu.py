@@ -210,3 +210,20 @@ def test_overfits_the_reference_fixture(sra):
         assert all(l == l for l in losses)                       # no NaN
         assert losses[-1] < 0.35 * losses[0], (dtype, losses[0], losses[-1])
         assert int(pv.argmax(1).eq(verb).sum()) == 5             # the five verbs are memorised
+
+
+def test_uint8_nhwc_input_equals_normalised_fp32_input(sra):
+    """Decoded uint8 images in (fused ToTensor+Normalize+layout kernel) == the reference's fp32 NCHW tensors in."""
+    g3 = load("g3_fcggnn_basic.npz")
+    net, _ = hip_fcggnn(sra, g3)
+    net.eval()
+    gen = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (5, 64, 64, 3), generator=gen, dtype=torch.uint8)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    f32 = ((u8.float() / 255.0 - mean) / std).permute(0, 3, 1, 2).contiguous()
+    verb = torch.arange(5).cuda()
+    with torch.no_grad():
+        a = net(u8.cuda(), verb)
+        b = net(f32.cuda(), verb)
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max()) < 1e-4
