@@ -589,7 +589,14 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   const int Nv = (p.N + 3) & ~3;
   const TO* const zeros = reinterpret_cast<const TO*>(p.zero_page);
 
+#ifdef SR_STAMPS
+  unsigned long long te_prep = 0, te_stats = 0, te_store = 0, te0 = 0, te1 = 0;
+  const bool estamp = (p.debug & 4) != 0;
+#endif
   auto epilogue = [&](int tile) {
+#ifdef SR_STAMPS
+    if (estamp) SR_STAMP(te0);
+#endif
     const int tm = tile / gn, tn = tile - tm * gn;
     const long m0 = (long)tm * BM;
     const int n0 = tn * BN;
@@ -618,35 +625,65 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
           for (int i = 0; i < FM; ++i) acc[j][i][r] *= e;
         }
     }
+#ifdef SR_STAMPS
+    if (estamp) { SR_STAMP(te1); te_prep += te1 - te0; te0 = te1; }
+#endif
     if (want_stats) {
       // pass 1 (column-major over the fragments, 8 live sums): per-channel sum / sum of squares of acc + bias over this
       // wave's 128 rows -> its own partial row [2*tm + wm] of `stats` (no LDS, no barrier: the two wave groups run
       // half a step apart and must not meet at a barrier here)
+      // Interior tiles without a bias (every train-mode convolution except at the edges) take a mask-free path on packed
+      // f32 math (v_pk_add_f32 / v_pk_fma_f32: two columns per instruction) -- this pass is pure VALU time, per tile.
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      const bool interior = (m0 + BM <= p.M) && (n0 + BN <= Nv) && !p.bias && !p.bias2;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        float s1[4], s2[4];
         const int nj = n0 + wn * FN * 16 + j * 16 + fgrp * 4;
-        const bool nok = nj < Nv;
+        if (interior) {
+          f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          const bool ok = nok && (m0 + wm * FM * 16 + i * 16 + frow < p.M);
+          for (int i = 0; i < FM; ++i) {
+            const f32x2_t v01 = {acc[j][i][0], acc[j][i][1]}, v23 = {acc[j][i][2], acc[j][i][3]};
+            a01 += v01; a23 += v23;
+            q01 = __builtin_elementwise_fma(v01, v01, q01);
+            q23 = __builtin_elementwise_fma(v23, v23, q23);
+          }
+          s1[0] = a01[0]; s1[1] = a01[1]; s1[2] = a23[0]; s1[3] = a23[1];
+          s2[0] = q01[0]; s2[1] = q01[1]; s2[2] = q23[0]; s2[3] = q23[1];
+        } else {
+          const bool nok = nj < Nv;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = ok ? acc[j][i][r] + bv[j][r] : 0.f;
-            s1[r] += v;
-            s2[r] += v * v;
+          for (int r = 0; r < 4; ++r) s1[r] = s2[r] = 0.f;
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            const bool ok = nok && (m0 + wm * FM * 16 + i * 16 + frow < p.M);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = ok ? acc[j][i][r] + bv[j][r] : 0.f;
+              s1[r] += v;
+              s2[r] += v * v;
+            }
           }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
         if (frow == 0) {
           float* row = p.stats + ((long)(tm * WAVES_M + wm) * 2) * p.N;
+          if (nj + 3 < p.N && (p.N & 3) == 0) {
+            *reinterpret_cast<float4*>(row + nj) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+            *reinterpret_cast<float4*>(row + p.N + nj) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (nj + r < p.N) { row[nj + r] = s1[r]; row[p.N + nj + r] = s2[r]; }
+            for (int r = 0; r < 4; ++r)
+              if (nj + r < p.N) { row[nj + r] = s1[r]; row[p.N + nj + r] = s2[r]; }
+          }
         }
       }
     }
+#ifdef SR_STAMPS
+    if (estamp) { SR_STAMP(te1); te_stats += te1 - te0; te0 = te1; }
+#endif
     // pass 2, i-major: one 16-row x 64-column strip of the wave's tile at a time
     if (!p.no_store) {
     // 16-bit outputs with a residual: the residual is NOT fetched in fragment layout (4 scattered columns per lane) but as
@@ -763,6 +800,9 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
       }
     }
     }
+#ifdef SR_STAMPS
+    if (estamp) { SR_STAMP(te1); te_store += te1 - te0; }
+#endif
   };
 
   // ---------------- phase offset between workgroups ----------------
@@ -892,6 +932,9 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   if (stamp && blockIdx.x < 256 && (threadIdx.x & 63) == 0) {
     unsigned long long* o = g_stamps + ((blockIdx.x * 8 + wave) & 2047) * 8;
     o[0] = tw; o[1] = tb; o[2] = 0; o[3] = tm_; o[4] = te; o[5] = (unsigned long long)total;
+#ifdef SR_STAMPS
+    o[2] = te_prep; o[6] = te_stats; o[7] = te_store;
+#endif
   }
 }
 
