@@ -121,6 +121,23 @@ int sr_bn_finalize(const float* stats, int tiles, int C, int64_t count, const fl
                    float* scale, float* shift, double* scratch, int scratch_rows, void* stream);
 /* scratch: caller-owned fp64 workspace [scratch_rows][2][C] (scratch_rows >= 1; 1024 rows use full parallelism)
  * for the deterministic two-stage reduction of the partials. */
+
+/* Train-mode BatchNorm statistics of a 1x1 / stride-1 convolution y = x W^T from the Gram matrix of its INPUT, so
+ * the convolution is not run for them (replaces launch 1 of the two-launch scheme above for the bottleneck expansion
+ * convs, where N = 4C):  sum_m y[m,n] = W[n,:].colsum(x),  sum_m y[m,n]^2 = W[n,:] (x^T x) W[n,:]^T.
+ *   sr_gram_plan        number of fp32 partials sr_gram writes for (M, C) and the floats per partial (C*C + C)
+ *   sr_gram             x [M, ldx] (bf16, C in {64,128,256,512}) -> partials [npartials][C*C + C]:
+ *                       per row slice, the C x C Gram block sums followed by the C column sums
+ *   sr_bn_finalize_gram reduces the partials in fp64, forms both sums per output channel of w [N, ldw] (bf16, the
+ *                       conv's packed weights) in fp64 and finishes exactly like sr_bn_finalize.
+ *                       scratch: fp64 workspace of at least 66*(C*C + C) elements. */
+int sr_gram_plan(int64_t M, int C, int64_t* npartials, int64_t* partial_floats);
+int sr_gram(const void* x, int64_t M, int C, int64_t ldx, int dtype, float* partials, int64_t npartials, void* stream);
+int sr_bn_finalize_gram(const float* partials, int64_t npartials, int C, const void* w, int64_t ldw, int N, int dtype,
+                        int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        float momentum, float eps, float* scale, float* shift, double* scratch, int64_t scratch_elems,
+                        void* stream);
+
 /* y = [relu]( x*scale[c] + shift[c] (+ res) ), rows x C, in place allowed. */
 int sr_bn_apply(const void* x, const float* scale, const float* shift, const void* res, void* y,
                 int64_t rows, int C, int relu, int dtype, void* stream);

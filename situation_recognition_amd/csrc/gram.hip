@@ -1,0 +1,346 @@
+// Train-mode BatchNorm statistics of a 1x1 convolution WITHOUT running the convolution.
+//
+// For y = x W^T (x: [M, C] NHWC pixels, W: [N, C]) the per-output-channel batch sums are
+//     sum_m y[m,n]   = W[n,:] . colsum(x)
+//     sum_m y[m,n]^2 = W[n,:] G W[n,:]^T        with the C x C Gram matrix  G = x^T x.
+// A bottleneck expansion conv has N = 4C, so G costs a quarter of the conv's MFMA work and reads x once; the
+// statistics-only conv launch it replaces ("two-launch BatchNorm") recomputed the whole product.
+//
+//   gram_kernel<P,TWO>  x -> per-(row slice, k-split) fp32 partial Gram blocks + column sums (MFMA, LDS-DMA ring)
+//   gram_reduce_kernel  fp32 partials -> fp64 (two deterministic stages, the layout bn_reduce uses)
+//   gram_project_kernel fp64 quadratic forms per output channel, then scale/shift/EMA exactly like bn_finalize_kernel
+//
+// The Gram sum runs over the pixel index m, so both MFMA operands are the SAME transposed fragment of x
+// ("8 consecutive pixels of one channel per lane"): it is read straight out of the row-major LDS image with
+// ds_read_b64_tr_b16, and because A and B use one k-order any pixel permutation inside a fragment is harmless.
+#include "common.h"
+
+namespace {
+
+__device__ __attribute__((aligned(256))) unsigned char g_gram_zero[256];
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+struct GramArgs {
+  const bf16_t* x;     // [M, ldx]
+  long M, ldx;
+  int C;
+  float* partials;     // [nslices * KS][C*C + C]
+  long pstride;        // C*C + C
+  long rows_per_wg;    // multiple of the stage height
+  const void* zero;    // 256 zero bytes
+};
+
+template <int N> __device__ __forceinline__ void gram_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// XOR applied to the 16-byte chunk index of LDS row `row` (even values: a transposed read takes chunk pairs).
+// The 8 rows one 32-lane half touches in a ds_read_b64_tr_b16 (row bits 0,1 and 3 vary) land on 8 distinct
+// 32-byte bank groups.  64-column panels have 128-byte rows, where row bit 0 already selects the bank half.
+template <int P> __device__ __forceinline__ int gram_swz(int row) {
+  if (P >= 128) return 2 * ((row & 3) | (((row >> 3) & 1) << 2));
+  return 2 * (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+}
+
+// P: panel width (channels a workgroup's Gram block spans per side).  TWO: C = 2P, the block's row and column
+// panels differ and are staged separately.  8 waves = RG row groups (32 channels of the A side each) x KS k-splits
+// (32-pixel sub-chunks of a stage); every stage is 16 KB per panel.
+template <int P, bool TWO>
+__global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
+  constexpr int KS = 256 / P, RG = P / 32, FB = P / 16, SR = 32 * KS;
+  constexpr int CPRW = P / 8, ROWB = P * 2, STAGE = SR * ROWB;
+  constexpr int NPAN = TWO ? 2 : 1, NS = TWO ? 4 : 8, IPS = 2 * NPAN;
+  constexpr int SLOT = STAGE * NPAN;
+  static_assert(STAGE == 16384, "stage");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rg = wave % RG, ks = wave / RG;
+  const int npan = TWO ? 2 : 1;
+  const int quad = blockIdx.x % (npan * npan);
+  const long slice = blockIdx.x / (npan * npan);
+  const int colA0 = (quad / npan) * P, colB0 = (quad % npan) * P;
+  const bool diag = colA0 == colB0;
+  const long r0 = slice * p.rows_per_wg;
+  const long r1 = min(p.M, r0 + p.rows_per_wg);
+  const int nst = (int)((r1 - r0 + SR - 1) / SR);
+
+  // ---- loader: chunk q = j*512 + tid of a stage; LDS position q*16, data chunk (q % CPRW) ^ swz(row)
+  long src_off[2];
+  int src_row[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = j * 512 + tid, row = q / CPRW, slot = q % CPRW;
+    src_row[j] = row;
+    src_off[j] = (long)row * p.ldx + ((slot ^ gram_swz<P>(row)) * 8);
+  }
+  auto issue = [&](int st) {
+    char* dst = smem + (st % NS) * SLOT + wave * 1024;
+    const long R = r0 + (long)st * SR;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = st < nst && R + src_row[j] < r1;
+      const bf16_t* base = p.x + R * p.ldx + src_off[j];
+      const bf16_t* sa = ok ? base + colA0 : (const bf16_t*)p.zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+      if (TWO) {
+        const bf16_t* sb = ok ? base + colB0 : (const bf16_t*)p.zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                         (__attribute__((address_space(3))) void*)(dst + STAGE + j * 8192), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- transposed-read addressing: lane (g = lane>>4, q = (lane>>2)&3, pp = lane&3) supplies row 8g+q (+4 for the
+  // second read), 8-byte piece pp of the block's 32-byte row segment
+  const int g = lane >> 4, tq = (lane >> 2) & 3, pp = lane & 3;
+  const int row0 = 32 * ks + 8 * g + tq;
+  const int fh = gram_swz<P>(row0) >> 1;
+  const int rd_base = row0 * ROWB + 16 * (pp >> 1) + 8 * (pp & 1);
+
+  auto frag = [&](const char* img, int cb) -> bf16x8_t {
+    const char* a = img + rd_base + 32 * (cb ^ fh);
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a + 4 * ROWB));
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  f32x4_t acc[2][FB], cs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    cs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < FB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+
+  // ---- pipeline: NS-1 stages in flight; issues past the slice's end read the zero page so the count stays fixed
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s);
+  for (int it = 0; it < nst; ++it) {
+    gram_wait_vm<(NS - 2) * IPS>();      // my pieces of stage `it` have landed
+    __builtin_amdgcn_s_barrier();        // everybody's have, and everybody finished reading stage it-1
+    issue(it + NS - 1);                  // refill the slot stage it-1 used
+    const char* imgA = smem + (it % NS) * SLOT;
+    const char* imgB = TWO ? imgA + STAGE : imgA;
+    bf16x8_t a[2];
+    a[0] = frag(imgA, 2 * rg);
+    a[1] = frag(imgA, 2 * rg + 1);
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+      const bf16x8_t b = frag(imgB, j);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b, acc[1][j], 0, 0, 0);
+    }
+    cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ones, cs[0], 0, 0, 0);
+    cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ones, cs[1], 0, 0, 0);
+  }
+  gram_wait_vm<0>();                     // drain the padding DMAs before the workgroup's LDS goes away
+
+  // ---- partial (slice, ks): lane holds D[a = 4g+r][b = lane&15]; stored transposed (G is used through the symmetric
+  // form only), so the four r values are one 16-byte store
+  float* out = p.partials + (slice * KS + ks) * p.pstride;
+  const int t = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = colA0 + 32 * rg + 16 * i + 4 * g;
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+      const int cb = colB0 + 16 * j + t;
+      *reinterpret_cast<float4*>(out + (long)cb * p.C + ca) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+    if (diag && t == 0)
+      *reinterpret_cast<float4*>(out + (long)p.C * p.C + ca) = make_float4(cs[i][0], cs[i][1], cs[i][2], cs[i][3]);
+  }
+}
+
+// Stage A: grid (E/256, chunks) -- fold a chunk of partials into fp64.  Stage B (chunks == 1 rows of scratch): same kernel
+// over the fp64 scratch.
+template <typename TI>
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const TI* __restrict__ in, long stride, int n, int per_chunk, long E,
+                                                          double* __restrict__ out) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int t0 = blockIdx.y * per_chunk, t1 = min(n, t0 + per_chunk);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int t = t0;
+  for (; t + 4 <= t1; t += 4) {
+    s0 += (double)in[(long)t * stride + e];
+    s1 += (double)in[(long)(t + 1) * stride + e];
+    s2 += (double)in[(long)(t + 2) * stride + e];
+    s3 += (double)in[(long)(t + 3) * stride + e];
+  }
+  for (; t < t1; ++t) s0 += (double)in[(long)t * stride + e];
+  out[(long)blockIdx.y * E + e] = (s0 + s1) + (s2 + s3);
+}
+
+// One workgroup per 8 output channels: s1 = w.cs, s2 = w G w in fp64, then the BatchNorm finalize of
+// bn_finalize_kernel (elementwise.hip) for those channels.
+__global__ __launch_bounds__(256) void gram_project_kernel(const double* __restrict__ G, const double* __restrict__ cs,
+                                                           const bf16_t* __restrict__ W, long ldw, int C, int N, double inv_count,
+                                                           double unbias, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ rmean,
+                                                           float* __restrict__ rvar, float momentum, float eps,
+                                                           float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double wl[512][8];
+  __shared__ double red[2][4][8];
+  const int n0 = blockIdx.x * 8, tid = threadIdx.x;
+  for (int i = tid; i < C * 8; i += 256) {
+    const int l = i >> 3, j = i & 7;
+    wl[l][j] = n0 + j < N ? (double)(float)W[(long)(n0 + j) * ldw + l] : 0.0;
+  }
+  __syncthreads();
+  double s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
+  for (int k = tid; k < C; k += 256) {
+    double a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.0;
+    for (int l = 0; l < C; ++l) {
+      const double gv = G[(long)l * C + k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = fma(gv, wl[l][j], a[j]);
+    }
+    const double ck = cs[k];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s2[j] = fma(a[j], wl[k][j], s2[j]);
+      s1[j] = fma(ck, wl[k][j], s1[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s1[j] += __shfl_xor(s1[j], o, 64);
+      s2[j] += __shfl_xor(s2[j], o, 64);
+    }
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][tid >> 6][j] = s1[j]; red[1][tid >> 6][j] = s2[j]; }
+  }
+  __syncthreads();
+  if (tid >= 8 || n0 + tid >= N) return;
+  const int c = n0 + tid;
+  const double t1 = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+  const double t2 = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+  const double mean = t1 * inv_count;
+  double var = t2 * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * unbias);
+}
+
+int gram_cus() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
+struct GramPlan { int P, KS, npan; long rows_per_wg, nslices, npartials; };
+
+bool gram_plan(int64_t M, int C, GramPlan* g) {
+  if (M <= 0 || (C != 64 && C != 128 && C != 256 && C != 512)) return false;
+  g->P = C > 256 ? 256 : C;
+  g->KS = 256 / g->P;
+  g->npan = C / g->P;
+  const long SR = 32 * g->KS;
+  const long ncu = gram_cus();
+  // one row slice per CU, but no fp32 accumulator sums more than 8192 pixels
+  const long cap = 8192 * g->KS;
+  const long rounds = (M + ncu * cap - 1) / (ncu * cap);
+  long rows = (M + ncu * rounds - 1) / (ncu * rounds);
+  rows = (rows + SR - 1) / SR * SR;
+  g->rows_per_wg = rows;
+  g->nslices = (M + rows - 1) / rows;
+  g->npartials = g->nslices * g->KS;
+  return true;
+}
+
+template <int P, bool TWO>
+int gram_launch(const GramArgs& a, const GramPlan& g, hipStream_t st) {
+  constexpr int LDS = 131072;
+  static bool once = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_kernel<P, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) ==
+           hipSuccess;
+  }();
+  if (!once) return SR_ERR_LAUNCH;
+  hipLaunchKernelGGL((gram_kernel<P, TWO>), dim3((unsigned)(g.nslices * g.npan * g.npan)), dim3(512), LDS, st, a);
+  return SR_OK;
+}
+
+}  // namespace
+
+extern "C" int sr_gram_plan(int64_t M, int C, int64_t* npartials, int64_t* partial_floats) {
+  GramPlan g;
+  if (!gram_plan(M, C, &g) || !npartials || !partial_floats) return SR_ERR_ARG;
+  *npartials = g.npartials;
+  *partial_floats = (int64_t)C * C + C;
+  return SR_OK;
+}
+
+extern "C" int sr_gram(const void* x, int64_t M, int C, int64_t ldx, int dtype, float* partials, int64_t npartials, void* stream) {
+  GramPlan g;
+  if (dtype != SR_BF16 || !x || !partials || !gram_plan(M, C, &g) || npartials != g.npartials || ldx < C || (ldx & 7) ||
+      ((uintptr_t)x & 15) || ((uintptr_t)partials & 15))
+    return SR_ERR_ARG;
+  static const void* zero = [] {
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_gram_zero)) != hipSuccess) z = nullptr;
+    return (const void*)z;
+  }();
+  if (!zero) return SR_ERR_LAUNCH;
+  GramArgs a;
+  a.x = (const bf16_t*)x; a.M = M; a.ldx = ldx; a.C = C; a.partials = partials; a.pstride = (long)C * C + C;
+  a.rows_per_wg = g.rows_per_wg; a.zero = zero;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  switch (C) {
+    case 64: rc = gram_launch<64, false>(a, g, st); break;
+    case 128: rc = gram_launch<128, false>(a, g, st); break;
+    case 256: rc = gram_launch<256, false>(a, g, st); break;
+    default: rc = gram_launch<256, true>(a, g, st); break;
+  }
+  if (rc != SR_OK) return rc;
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+extern "C" int sr_bn_finalize_gram(const float* partials, int64_t npartials, int C, const void* w, int64_t ldw, int N, int dtype,
+                                   int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, float* scale, float* shift, double* scratch, int64_t scratch_elems,
+                                   void* stream) {
+  if (dtype != SR_BF16 || !partials || npartials <= 0 || !w || N <= 0 || ldw < C || count <= 0 || !gamma || !beta || !scale || !shift ||
+      !scratch || (C != 64 && C != 128 && C != 256 && C != 512))
+    return SR_ERR_ARG;
+  const long E = (long)C * C + C;
+  int chunks = (int)((npartials + 15) / 16);
+  if (chunks > 64) chunks = 64;
+  const int per = (int)((npartials + chunks - 1) / chunks);
+  chunks = (int)((npartials + per - 1) / per);
+  if (scratch_elems < (long)(chunks + 1) * E) return SR_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  double* stageA = scratch + E;   // [chunks][E]; final fp64 G | colsum at scratch[0..E)
+  const unsigned gx = (unsigned)((E + 255) / 256);
+  hipLaunchKernelGGL(gram_reduce_kernel<float>, dim3(gx, chunks), dim3(256), 0, st, partials, E, (int)npartials, per, E, stageA);
+  hipLaunchKernelGGL(gram_reduce_kernel<double>, dim3(gx, 1), dim3(256), 0, st, (const double*)stageA, E, chunks, chunks, E, scratch);
+  const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+  hipLaunchKernelGGL(gram_project_kernel, dim3((N + 7) / 8), dim3(256), 0, st, (const double*)scratch, (const double*)(scratch + (long)C * C),
+                     (const bf16_t*)w, (long)ldw, C, N, 1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps,
+                     scale, shift);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}

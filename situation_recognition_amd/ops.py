@@ -164,6 +164,47 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
     return scale, shift
 
 
+_GRAM_SCRATCH = {}
+
+
+def gram_plan(M, Cc):
+    """(number of partials, floats per partial) `gram` writes for an [M, Cc] input."""
+    import ctypes
+    n, f = ctypes.c_int64(), ctypes.c_int64()
+    check(lib().sr_gram_plan(int(M), int(Cc), ctypes.byref(n), ctypes.byref(f)), "sr_gram_plan")
+    return n.value, f.value
+
+
+def gram(x2d):
+    """Per-slice partial Gram matrices + column sums of x2d [M, C] (bf16, C in 64/128/256/512)."""
+    require_gpu(x2d)
+    M, Cc = x2d.shape
+    n, f = gram_plan(M, Cc)
+    part = torch.empty((n, f), device=x2d.device, dtype=torch.float32)
+    check(_timed("gram", 0.0, 2.0 * M * Cc, lambda: lib().sr_gram(x2d.data_ptr(), M, Cc, x2d.stride(0), dtype_code(x2d.dtype),
+                                                                 part.data_ptr(), n, stream())), "sr_gram")
+    return part
+
+
+def bn_finalize_gram(part, w, count, gamma, beta, running_mean, running_var, momentum, eps):
+    """Train-mode BN scale/shift (+ EMA) of the 1x1 conv with packed weights w [N, C] whose input has the partial Grams `part`."""
+    require_gpu(part, w, gamma, beta, running_mean, running_var)
+    N, Cc = w.shape
+    E = Cc * Cc + Cc
+    scale = torch.empty(N, device=part.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    key = (part.device, torch.cuda.current_stream().cuda_stream)
+    scratch = _GRAM_SCRATCH.get(key)
+    if scratch is None or scratch.numel() < 66 * E:
+        scratch = torch.empty(66 * (512 * 512 + 512), device=part.device, dtype=torch.float64)
+        _GRAM_SCRATCH[key] = scratch
+    check(lib().sr_bn_finalize_gram(part.data_ptr(), part.shape[0], Cc, w.data_ptr(), w.stride(0), N, dtype_code(w.dtype), int(count),
+                                    gamma.data_ptr(), beta.data_ptr(), ptr(running_mean), ptr(running_var), float(momentum),
+                                    float(eps), scale.data_ptr(), shift.data_ptr(), scratch.data_ptr(), scratch.numel(), stream()),
+          "sr_bn_finalize_gram")
+    return scale, shift
+
+
 def bn_apply(x, scale, shift, res=None, relu=True, out=None):
     require_gpu(x, scale, shift, res)
     out = torch.empty_like(x) if out is None else out

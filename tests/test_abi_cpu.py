@@ -44,6 +44,20 @@ def test_argument_validation_needs_no_gpu(libpath):
     assert l.sr_gemm_stats_tiles(1204224, 256) == 2 * 4704
     assert l.sr_gemm_stats_tiles(1204224, 64) == 4 * 4704
 
+
+def test_gram_plan_needs_no_gpu(libpath):
+    """Row slices of the Gram statistics kernel: one per CU (256 assumed without a device), split further so that no
+    fp32 accumulator sums more than 8192 pixels; 64/128-wide inputs write 4/2 k-split partials per slice."""
+    from situation_recognition_amd import _lib
+    l = _lib.lib()
+    n, f = ctypes.c_int64(), ctypes.c_int64()
+    assert l.sr_gram_plan(1204224, 256, ctypes.byref(n), ctypes.byref(f)) == 0 and (n.value, f.value) == (256, 256 * 256 + 256)
+    assert l.sr_gram_plan(19267584, 64, ctypes.byref(n), ctypes.byref(f)) == 0 and (n.value, f.value) == (768 * 4, 64 * 64 + 64)
+    assert l.sr_gram_plan(37, 512, ctypes.byref(n), ctypes.byref(f)) == 0 and (n.value, f.value) == (2, 512 * 512 + 512)
+    assert l.sr_gram_plan(100, 96, ctypes.byref(n), ctypes.byref(f)) == -1
+    assert l.sr_gram(None, 100, 64, 64, 1, None, 4, None) == -1
+
+
 def test_no_cpu_fallback():
     from situation_recognition_amd._lib import SrError
     from situation_recognition_amd.imsitu_encoder import imsitu_encoder

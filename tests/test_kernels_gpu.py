@@ -177,6 +177,53 @@ def test_batchnorm_train_two_launch_conv(ops, dtype):
     assert (rm_d.cpu() - rm_ref).abs().max() < 2e-3 and (rv_d.cpu() - rv_ref).abs().max() < 2e-3
 
 
+@pytest.mark.parametrize("M,C", [(980, 64), (70001, 64), (980, 128), (33333, 128), (37, 256), (980, 256), (50000, 256),
+                                 (245, 512), (9000, 512)])
+def test_gram_partials_sum_to_xtx(ops, M, C):
+    """sr_gram: the partials add up to x^T x and colsum(x) (ragged row counts: the last stage of the last slice is
+    padded from the zero page); bf16 products are exact in fp32, so only the fp32 accumulation order differs."""
+    x = rnd(M, C, dtype=torch.bfloat16, seed=M + C)
+    x[:, C - 3] = 0                                        # a padded (all-zero) channel
+    part = ops.gram(x.cuda())
+    n, f = ops.gram_plan(M, C)
+    assert part.shape == (n, f) and f == C * C + C
+    tot = part.double().sum(0).cpu()
+    xd = x.double()
+    G = xd.t() @ xd
+    tol = 1e-5 * float(G.diagonal().max())
+    assert (tot[: C * C].view(C, C) - G).abs().max() < tol
+    assert (tot[C * C:] - xd.sum(0)).abs().max() < 1e-5 * float(xd.abs().sum(0).max())
+    assert float(tot[: C * C].view(C, C)[C - 3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,W,Cin", [(3, 10, 9, 64), (2, 14, 14, 256), (5, 7, 7, 512), (6, 28, 28, 128)])
+def test_batchnorm_train_gram_statistics(ops, B, H, W, Cin):
+    """Expansion conv (N = 4C): scale/shift/EMA from the input's Gram matrix equal the ones the statistics-only conv
+    launch gives, and the fused second launch reproduces F.batch_norm(train) + identity + ReLU."""
+    dtype, Cout = torch.bfloat16, 4 * Cin
+    x = F.relu(rnd(B, Cin, H, W, dtype=dtype, seed=1)) + 0.25         # post-ReLU input with a non-zero mean
+    x = x.to(dtype)
+    w = rnd(Cout, Cin, 1, 1, dtype=dtype, seed=2, scale=2.0 / Cin ** 0.5)
+    idn = rnd(B, H, W, Cout, dtype=dtype, seed=5)
+    gamma, beta = 0.5 + torch.rand(Cout), rnd(Cout, seed=3, scale=0.2)
+    rm, rv = rnd(Cout, seed=4, scale=0.1), 0.5 + torch.rand(Cout)
+    conv = F.conv2d(x.float(), w.float())
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.relu(F.batch_norm(conv, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+                 + idn.float().permute(0, 3, 1, 2))
+    xh, wp = x.permute(0, 2, 3, 1).contiguous().cuda(), pack_w(w).cuda()
+    rm_d, rv_d = rm.cuda(), rv.cuda()
+    part = ops.gram(xh.view(-1, Cin))
+    scale, shift = ops.bn_finalize_gram(part, wp.view(Cout, Cin), B * H * W, gamma.cuda(), beta.cuda(), rm_d, rv_d, 0.1, 1e-5)
+    st = ops.conv2d(xh, wp, Cout, 1, 1, 0, stats_only=True)
+    scale2, shift2 = ops.bn_finalize(st, B * H * W, gamma.cuda(), beta.cuda(), None, None, 0.1, 1e-5)
+    assert ((scale - scale2).abs() / scale2.abs().clamp_min(1e-3)).max() < 2e-5
+    assert (shift - shift2).abs().max() < 2e-4
+    y = ops.conv2d(xh, wp, Cout, 1, 1, 0, bias=shift, escale=scale, res=idn.cuda(), relu=True)
+    close(y.permute(0, 3, 1, 2), ref, dtype, k=2.0)
+    assert (rm_d.cpu() - rm_ref).abs().max() < 2e-3 and (rv_d.cpu() - rv_ref).abs().max() < 2e-3
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_pools(ops, dtype):
     x = rnd(3, 64, 13, 17, dtype=dtype, seed=1)
