@@ -421,12 +421,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(c
 // v3: 256x256 tile, 8 waves (2 x 4, each 128 x 64 = 8 x 4 MFMA fragments), for N > 128.
 //
 // Same persistent stream of K-steps as v2, but
-//   * K-step = 64-byte rows (32 bf16 / 16 f32); the ring has FOUR 32 KiB slots, so THREE steps (96 KiB) are in
-//     flight per CU; a 256x256 tile needs 1.5x fewer LDS-DMA bytes per FLOP than 256x128;
-//   * the fragments of step s+1 are read from LDS WHILE the MFMAs of step s run ("rolling" A registers: a[i] is
-//     reloaded as soon as its four MFMAs have issued; B is double-buffered), so no LDS latency is exposed at the
-//     step boundary and the top-of-step synchronisation is for the data of step s+1, one step ahead;
-//   * 12 ds_read_b128 per 32 MFMAs instead of 16.
+//   * K-step = 64-byte rows (32 bf16 / 16 f32); the ring has FOUR 32 KiB slots, THREE steps (96 KiB) in flight per CU;
+//     a 256x256 tile needs 1.5x fewer LDS-DMA bytes per FLOP than 256x128;
+//   * every DMA piece is a `buffer_load_dwordx4 ... lds` with a scalar K offset (no vector address arithmetic per step);
+//   * the K loop is straight-line: wait, barrier, 4 DMA pieces, 12 ds_read_b128, 32 MFMAs, and a scalar countdown to the
+//     next tap / pair / tile change.  Measured against it on this kernel (tools/bench_gemm.py, same run):
+//       - "rolling" fragment prefetch (step s+1's fragments read between the MFMAs of step s): 10-15 % slower on the convs:
+//         the conditional reloads chop the MFMA stream into ~30 basic blocks per step;
+//       - two wave groups half a step apart (one loads while the other multiplies, two barriers per step): equal to
+//         rolling; its load section was dominated by scalar bookkeeping, not by LDS or DMA latency;
+//       - in-kernel stamps + a skeleton of this loop (tools/ubench/dma_shapes.hip) put the step at ~1700 cycles for
+//         1024 MFMA-pipe cycles; at that point the chip is power-limited on random operands (the clock drops from 2.3 to
+//         ~2.0 GHz), i.e. ~1.2 PFLOP/s is the practical ceiling of this tile shape, not 2.5.
 // 64-byte rows: 16-byte chunk c of row r is stored at chunk position c ^ ((r & 8) >> 2)  (conflict-free for the
 // ds_read_b128 lane groups, checked by enumeration); one DMA piece = 16 rows x 64 B.
 // =====================================================================================================
@@ -459,7 +465,6 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int ecol = ((lane & 3) ^ ((lane >> 5) << 1)) * EPC;       // source chunk (swizzled) -> element offset
   const int fsw = ((lane >> 4) ^ ((lane & 8) >> 2)) << 4;         // fragment read: byte offset inside the 64-B row
 
   const int gn = (p.N + BN - 1) / BN, gm = (p.M + BM - 1) / BM;
@@ -477,10 +482,18 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   const int total = my_tiles * nkt;
 
   // ---------------- loader: per-lane base pointers, rebuilt only when the tile or the operand pair changes ----------------
+  // Every piece is one `buffer_load_dwordx4 ... lds`: the tile's buffer descriptor (scalar), a loop-invariant 32-bit
+  // per-lane row offset and a per-step SCALAR K offset.  No vector instruction computes an address inside the K loop
+  // (an LDS-DMA with 64-bit per-lane pointers cost 6-8 VALU instructions per piece for the conv's tap offset and zero-page
+  // select, issued in the matrix cores' shadow but competing for the same issue port).  Rows past M / N and padding taps
+  // are given the offset 0x80000000, beyond num_records: the buffer load then writes zeros to LDS.
   int ld_tile = vb, ld_kt = 0, ld_pr = 0, ld_k0 = 0;   // ld_k0: first K-step of the current pair
-  const T* a_ptr[A_PER];
-  const T* w_ptr[B_PER];
+  constexpr int OOB = (int)0x80000000;
+  constexpr int NREC = 0x7ffff000;
+  int a_vo[A_PER], w_vo[B_PER];
   unsigned a_mask[A_PER];
+  __amdgpu_buffer_rsrc_t srd_a, srd_w;
+  const bool taps = CONV && (p.kp[0].K >> p.cv.lgCseg) > 1;   // per-tap validity masks are needed
   auto setup_ptrs = [&](int tile, int pr) {
     const int tm = tile / gn, tn = tile - tm * gn;
     const long m0 = (long)tm * BM;
@@ -495,22 +508,36 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     kp.lda = pr == 0 ? p.kp[0].lda : (pr == 1 ? p.kp[1].lda : p.kp[2].lda);
     kp.ldw = pr == 0 ? p.kp[0].ldw : (pr == 1 ? p.kp[1].ldw : p.kp[2].ldw);
     kp.K = pr == 0 ? p.kp[0].K : (pr == 1 ? p.kp[1].K : p.kp[2].K);
+    // input pixel (tap 0) of output row m, relative to the tensor start; increasing in m
+    auto pixel = [&](long m) -> long {
+      const unsigned hw = (unsigned)(p.cv.Ho * p.cv.Wo), um = (unsigned)m;
+      const long b = um / hw;
+      const int rem = (int)(um - (unsigned)b * hw);
+      const int ho = rem / p.cv.Wo, wo = rem - ho * p.cv.Wo;
+      return (b * p.cv.H + (ho * p.cv.stride - p.cv.pad)) * (long)p.cv.Wd + (wo * p.cv.stride - p.cv.pad);
+    };
+    const long pix0 = CONV ? pixel(m0) : 0;              // wave-uniform
+    const long abase = CONV ? pix0 * p.cv.cpix : m0 * kp.lda;
+    srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)kp.A + abase), 0, NREC, 0x00020000);
+    srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)kp.W + (long)n0 * kp.ldw), 0, NREC, 0x00020000);
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-      const long m = m0 + (wave + i * NW) * 16 + prow;
-      if (!CONV) {
-        a_ptr[i] = (const T*)kp.A + (m < p.M ? m : (long)p.M - 1) * kp.lda + ec;
-        a_mask[i] = 0xffffffffu;
-      } else if (m >= p.M) {
-        a_ptr[i] = (const T*)kp.A;
+      const int r = (wave + i * NW) * 16 + prow;
+      const long m = m0 + r;
+      if (m >= p.M) {
+        a_vo[i] = OOB;
         a_mask[i] = 0;
+      } else if (!CONV) {
+        a_vo[i] = (int)((r * kp.lda + ec) * (long)sizeof(T));
+        a_mask[i] = 0xffffffffu;
       } else {
         const unsigned hw = (unsigned)(p.cv.Ho * p.cv.Wo), um = (unsigned)m;
         const long b = um / hw;
         const int rem = (int)(um - (unsigned)b * hw);
         const int ho = rem / p.cv.Wo, wo = rem - ho * p.cv.Wo;
         const int hi0 = ho * p.cv.stride - p.cv.pad, wi0 = wo * p.cv.stride - p.cv.pad;
-        a_ptr[i] = (const T*)kp.A + ((b * p.cv.H + hi0) * (long)p.cv.Wd + wi0) * p.cv.cpix + ec;
+        const long pix = (b * p.cv.H + hi0) * (long)p.cv.Wd + wi0;
+        a_vo[i] = (int)(((pix - pix0) * p.cv.cpix + ec) * (long)sizeof(T));
         const int ntap = kp.K >> p.cv.lgCseg;
         unsigned mk = 0;
         for (int t = 0; t < ntap; ++t) {
@@ -519,57 +546,31 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
           if (hi >= 0 && hi < p.cv.H && wi >= 0 && wi < p.cv.Wd) mk |= 1u << t;
         }
         a_mask[i] = mk;
+        if (ntap == 1 && mk == 0) a_vo[i] = OOB;
       }
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
-      const int n = n0 + (wave + i * NW) * 16 + prow;
-      w_ptr[i] = (const T*)kp.W + (long)(n < p.N ? n : p.N - 1) * kp.ldw + ec;
+      const int r = (wave + i * NW) * 16 + prow;
+      w_vo[i] = n0 + r < p.N ? (int)((r * kp.ldw + ec) * (long)sizeof(T)) : OOB;
     }
   };
   setup_ptrs(ld_tile, 0);
 
   // scalar (wave-uniform) description of the step being issued; computed once per step
-  long st_aoff = 0, st_woff = 0;
+  int st_aoff = 0, st_woff = 0;                // byte offsets (scalar)
   int st_tap = 0, st_slot = 0;
-  auto begin_issue = [&](int slot) {
-    const int kl = ld_kt - ld_k0;               // K-step inside the current pair
-    const int k = kl * BK;
-    st_slot = slot;
-    st_woff = k;
-    if (CONV) {
-      st_tap = k >> p.cv.lgCseg;               // uniform: BK <= Cseg
-      const int cc = k & ((1 << p.cv.lgCseg) - 1);
-      const int dh = p.cv.KW == 1 ? st_tap : (st_tap * 11) >> 5, dw = st_tap - dh * p.cv.KW;
-      st_aoff = ((long)dh * p.cv.Wd + dw) * p.cv.cpix + cc;
-    } else {
-      st_aoff = k;
-    }
-  };
   auto issue_piece = [&](int q) {              // q < A_PER: A pieces; then B pieces
     char* dst = smem + st_slot * SLOT + (q >= A_PER ? BM * 64 + (wave + (q - A_PER) * NW) * 1024 : (wave + q * NW) * 1024);
-    const T* src;
     if (q < A_PER) {
-      src = a_ptr[q < A_PER ? q : 0] + st_aoff;
-      if (CONV) src = ((a_mask[q < A_PER ? q : 0] >> st_tap) & 1) ? src : (const T*)p.zero_page;
+      int vo = a_vo[q < A_PER ? q : 0];
+      if (taps) vo = ((a_mask[q < A_PER ? q : 0] >> st_tap) & 1) ? vo : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (__attribute__((address_space(3))) void*)dst, 16, vo, st_aoff, 0, 0);
     } else {
-      src = w_ptr[q >= A_PER ? q - A_PER : 0] + st_woff;
-    }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
-  auto end_issue = [&]() {
-    if (++ld_kt == nkt) {
-      ld_kt = 0; ld_pr = 0; ld_k0 = 0;
-      ld_tile += G;
-      if (ld_tile < ntiles) setup_ptrs(ld_tile, 0);
-    } else if (ld_pr + 1 < p.npairs && ld_kt - ld_k0 == (ld_pr == 0 ? p.nk[0] : p.nk[1])) {
-      ld_k0 = ld_kt;
-      ++ld_pr;
-      setup_ptrs(ld_tile, ld_pr);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (__attribute__((address_space(3))) void*)dst, 16, w_vo[q >= A_PER ? q - A_PER : 0],
+                                               st_woff, 0, 0);
     }
   };
-
   f32x4_t acc[FN][FM];  // [n-fragment j][m-fragment i]
   auto clear_acc = [&]() {
 #pragma unroll
@@ -604,25 +605,42 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     const int el = fresh_lane();
     const int frow = el & 15, fgrp = el >> 4;
     TO* const trash = reinterpret_cast<TO*>((char*)p.trash_page + el * 16);
+    // per-column vectors: a lane's four columns of a fragment are consecutive, so interior tiles fetch them as one
+    // 16-byte load per fragment column block (4 loads instead of 16 per vector, all issued before the first is used)
+    const bool nvec = (n0 + BN <= p.N) && ((p.N & 3) == 0);
     float bv[FN][4];
+    auto colvec = [&](const float* v, float (&out)[FN][4]) {
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
+      for (int j = 0; j < FN; ++j) {
+        const int nj = n0 + wn * FN * 16 + j * 16 + fgrp * 4;
+        if (nvec) {
+          const float4 q = *reinterpret_cast<const float4*>(v + nj);
+          out[j][0] = q.x; out[j][1] = q.y; out[j][2] = q.z; out[j][3] = q.w;
+        } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wn * FN * 16 + j * 16 + fgrp * 4 + r;
-        const int nn = n < p.N ? n : p.N - 1;
-        bv[j][r] = (p.bias ? p.bias_scale * p.bias[nn] : 0.f) + (p.bias2 ? p.bias2[nn] : 0.f);
+          for (int r = 0; r < 4; ++r) out[j][r] = v[nj + r < p.N ? nj + r : p.N - 1];
+        }
       }
+    };
+    {
+      float b1[FN][4], b2[FN][4];
+      if (p.bias) colvec(p.bias, b1);
+      if (p.bias2) colvec(p.bias2, b2);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[j][r] = (p.bias ? p.bias_scale * b1[j][r] : 0.f) + (p.bias2 ? b2[j][r] : 0.f);
+    }
     const bool scaled = p.escale != nullptr;
     if (scaled) {  // fold the multiplier into the accumulators once (registers: none extra)
+      float ev[FN][4];
+      colvec(p.escale, ev);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int n = n0 + wn * FN * 16 + j * 16 + fgrp * 4 + r;
-          const float e = p.escale[n < p.N ? n : p.N - 1];
 #pragma unroll
-          for (int i = 0; i < FM; ++i) acc[j][i][r] *= e;
+          for (int i = 0; i < FM; ++i) acc[j][i][r] *= ev[j][r];
         }
     }
 #ifdef SR_STAMPS
@@ -690,9 +708,11 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     // whole 16-byte row chunks, coalesced, one strip ahead, and added (+ReLU) after the LDS transpose, on the output rows.
     constexpr bool ROWRES = STAGED && EPI == 0;
     const bool rowres = ROWRES && p.res != nullptr;
-    uint4 rnext[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) rnext[h] = make_uint4(0, 0, 0, 0);
+    // The residual is requested RD strips ahead (RD*NH 16-byte loads per lane in flight, in the registers the K loop's
+    // fragments no longer need): one strip ahead left every strip waiting a full HBM latency for its residual; all FM
+    // strips at once spills.
+    constexpr int RD = FM < 3 ? FM : 3;
+    uint4 rall[RD][NH];
     auto fetch_res = [&](int i, uint4 (&dst)[NH]) {
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
@@ -703,13 +723,16 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         dst[h] = *reinterpret_cast<const uint4*>(okk ? (const char*)((const TO*)p.res + mm * p.ldres + nn) : (const char*)p.zero_page);
       }
     };
-    if (rowres) fetch_res(0, rnext);
+    if (rowres) {
+#pragma unroll
+      for (int i = 0; i < RD; ++i) fetch_res(i, rall[i]);
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       uint4 rcur[NH];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) rcur[h] = rnext[h];
-      if (rowres && i + 1 < FM) fetch_res(i + 1, rnext);
+      for (int h = 0; h < NH; ++h) rcur[h] = rowres ? rall[i % RD][h] : make_uint4(0, 0, 0, 0);
+      if (rowres && i + RD < FM) fetch_res(i + RD, rall[i % RD]);
       const long m = m0 + wm * FM * 16 + i * 16 + frow;
       char* stg = smem + STG_OFF + wave * (16 * CPR * 16);  // per-wave [16 rows][16*FN cols] 16-bit strip; 16-B chunk c of row r at c ^ (r & (CPR-1))
 #pragma unroll
@@ -822,120 +845,133 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     while (__builtin_amdgcn_s_memtime() - t_start < delay) __builtin_amdgcn_s_sleep(32);
   }
 
-  // ---------------- prologue: up to 4 steps in flight, fragments of step 0 into registers ----------------
-  int issued = 0;
-  for (; issued < NSLOT && issued < total; ++issued) {
-    begin_issue(issued);
+  // ---------------- K loop ----------------
+  // One barrier per step, everything else straight-line:
+  //     wait (my pieces of step s) ; barrier ; issue the pieces of step s+D ; read the 12 fragments of step s ; 32 MFMAs
+  // D = NSLOT-1 steps of LDS-DMA stay in flight.  The slot refilled at step s is the one step s-1 was read from: every
+  // wave has issued the MFMAs that consumed those reads before it reaches this step's barrier.  The loader's state is
+  // scalar and incremental -- two byte offsets that advance by one K-step, and a countdown to the next "segment" change
+  // (conv tap, operand pair, tile) where they are recomputed -- because scalar bookkeeping in front of the matrix
+  // instructions is not free: 60 dependent SALU instructions per step cost ~340 cycles of a ~1700-cycle step
+  // (tools/ubench/dma_shapes.hip), and the fully general per-step form of this loop used about that many.
+  {
+    constexpr int D = NSLOT - 1;
+    static_assert((D - 1) * L + S < 64, "vmcnt is a 6-bit counter");
+    constexpr int STEPB = BK * (int)sizeof(T);
+    int seg_left = 0;
+    auto refresh = [&]() {                       // offsets and countdown for the step (ld_tile, ld_pr, ld_kt)
+      const int kl = ld_kt - ld_k0;
+      const int k = kl * BK;
+      const int plen = ld_pr == 0 ? p.nk[0] : (ld_pr == 1 ? p.nk[1] : p.nk[2]);
+      seg_left = plen - kl;
+      st_woff = k * (int)sizeof(T);
+      if (CONV) {
+        st_tap = k >> p.cv.lgCseg;
+        const int cc = k & ((1 << p.cv.lgCseg) - 1);
+        const int dh = p.cv.KW == 1 ? st_tap : (st_tap * 11) >> 5, dw = st_tap - dh * p.cv.KW;
+        st_aoff = ((dh * p.cv.Wd + dw) * p.cv.cpix + cc) * (int)sizeof(T);
+        const int tleft = ((1 << p.cv.lgCseg) - cc) / BK;
+        seg_left = tleft < seg_left ? tleft : seg_left;
+      } else {
+        st_aoff = st_woff;
+      }
+    };
+    auto advance = [&]() {
+      ++ld_kt;
+      if (--seg_left > 0) { st_aoff += STEPB; st_woff += STEPB; return; }
+      if (ld_kt == nkt) {
+        ld_kt = 0; ld_pr = 0; ld_k0 = 0;
+        ld_tile += G;
+        if (ld_tile < ntiles) setup_ptrs(ld_tile, 0);
+      } else if (ld_kt - ld_k0 == (ld_pr == 0 ? p.nk[0] : (ld_pr == 1 ? p.nk[1] : p.nk[2]))) {
+        ld_k0 = ld_kt;
+        ++ld_pr;
+        setup_ptrs(ld_tile, ld_pr);
+      }
+      refresh();
+    };
+    auto issue_step = [&](int slot) {
+      st_slot = slot;
 #pragma unroll
-    for (int q = 0; q < L; ++q) issue_piece(q);
-    end_issue();
-  }
-  if (issued >= 4) wait_vm<3 * L>(); else if (issued == 3) wait_vm<2 * L>(); else if (issued == 2) wait_vm<L>(); else wait_vm<0>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  Frag<T> a[FM], b[FN], bs[2];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) a[i] = rdA(0, i);
-#pragma unroll
-  for (int j = 0; j < FN; ++j) b[j] = rdB(0, j);
-  bs[0] = b[FN - 2]; bs[1] = b[FN - 1];
-
-  int c_tile = vb, c_kt = 0;
-  bool stored = false;
-  #ifdef SR_STAMPS
-  const bool stamp = (p.debug & 4) != 0;
-#else
-  constexpr bool stamp = false;
+      for (int q = 0; q < L; ++q) issue_piece(q);
+      advance();
+    };
+    refresh();
+    int issued = 0;
+    for (; issued < D && issued < total; ++issued) issue_step(issued);
+    int c_tile = vb, c_left = nkt, since_epi = 0;
+    // (the +S stores of an epilogue are younger than the pieces of the next D steps: their waits may leave them in flight)
+    auto slow_wait = [&](int later) {
+      const bool st = since_epi > 0 && !two && S > 0;
+      if (since_epi > 0) --since_epi;
+      if (st) {
+        if (later >= 2) wait_vm<2 * L + S>(); else if (later == 1) wait_vm<L + S>(); else wait_vm<S>();
+      } else {
+        if (later >= 2) wait_vm<2 * L>(); else if (later == 1) wait_vm<L>(); else wait_vm<0>();
+      }
+    };
+#ifdef SR_STAMPS
+    const bool stamp = (p.debug & 4) != 0;
+    unsigned long long tw = 0, tb = 0, tm_ = 0, te = 0, t0 = 0, t1 = 0;
 #endif
-  unsigned long long tw = 0, tb = 0, tm_ = 0, te = 0, t0 = 0, t1 = 0;
-
-  // wait until my DMA pieces of step k have landed: ops younger than them = later groups (+ the stores of an epilogue
-  // issued since; counted once -- afterwards the plain count is merely stricter)
-  auto wait_step = [&](int k) {
-    if (k >= total) return;
-    const int later = issued - k - 1;  // 0..2
-    if (stored && !two && S > 0) {
-      if (later >= 2) wait_vm<2 * L + S>(); else if (later == 1) wait_vm<L + S>(); else wait_vm<S>();
-    } else {
-      if (later >= 2) wait_vm<2 * L>(); else if (later == 1) wait_vm<L>(); else wait_vm<0>();
-    }
-    stored = false;
-  };
-  // (A variant that ran waves 4-7 half a step behind waves 0-3, two barriers per step, was measured 1.4x SLOWER:
-  //  every extra barrier drains the rolling LDS reads.  One barrier per 32 MFMAs it is.)
-  for (int s = 0; s < total; ++s) {
-    const bool has_next = s + 1 < total;
-    const bool tile_end = (c_kt + 1 == nkt);
-    const bool roll = has_next && !tile_end;  // across a tile end the fragments are fetched after the epilogue (registers)
-    const int nslot = (s + 1) % NSLOT;
-    bool do_issue = false;
-    if (stamp) SR_STAMP(t0);
-    if (has_next) {
-      wait_step(s + 1);              // my pieces of step s+1 have landed
+    Frag<T> a[FM], b[FN];
+    int slot = 0, islot = D % NSLOT;
+    for (int s = 0; s < total; ++s) {
+#ifdef SR_STAMPS
+      if (stamp) SR_STAMP(t0);
+#endif
+      if (since_epi == 0 && issued - s == D && D == 3) wait_vm<2 * L>();
+      else if (since_epi == 0 && issued - s == D && D == 2) wait_vm<L>();
+      else slow_wait(issued - s - 1);
+#ifdef SR_STAMPS
       if (stamp) { SR_STAMP(t1); tw += t1 - t0; }
-      lds_barrier();                 // everybody's have; my reads of slot s%4 are complete (lgkmcnt 0) -> it may be refilled
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef SR_STAMPS
       if (stamp) { SR_STAMP(t0); tb += t0 - t1; }
-      if (issued < total) { do_issue = true; begin_issue(issued % NSLOT); }
-    }
-    // 32 MFMAs in two sweeps over the 8 row fragments: sweep 0 uses b[0], b[1], sweep 1 uses b[2], b[3].  In sweep 1 every
-    // a[i] dies after its two MFMAs and is reloaded for step s+1 on the spot; b[0], b[1] (dead after sweep 0) are reloaded in
-    // sweep 1 as well; only b[2], b[3] of the next step need spare registers (bs).  The 4 DMA instructions of step s+4
-    // are issued in sweep 0.
-    // (Specialising this block four ways on (roll, do_issue) to drop the uniform branches made hipcc spill ~200 registers
-    //  and ran 20x slower; the branches stay.)
-    // FN/2 sweeps over the FM row fragments; sweep k multiplies with b[2k], b[2k+1].  Fragments are re-read for step s+1 as
-    // soon as they are dead: b[2k-2], b[2k-1] during sweep k; a[i] during the last sweep; the last B pair through spares.
-    if (p.debug & 16) __builtin_amdgcn_s_setprio(1);
+#endif
+      if (issued < total) {
+        issue_step(islot);
+        ++issued;
+        islot = islot + 1 == NSLOT ? 0 : islot + 1;
+      }
 #pragma unroll
-    for (int k = 0; k < FN / 2; ++k) {
+      for (int j = 0; j < FN; ++j) b[j] = rdB(slot, j);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        mma<T>(b[2 * k], a[i], acc[2 * k][i]);
-        mma<T>(b[2 * k + 1], a[i], acc[2 * k + 1][i]);
-        if (k == 0 && i < L && do_issue) issue_piece(i);
-        if (roll) {
-          if (k == FN / 2 - 1) {
-            a[i] = rdA(nslot, i);
-          } else {
-            if (k == FN / 2 - 2 && i == FM / 2) bs[0] = rdB(nslot, FN - 2);
-            if (k == FN / 2 - 2 && i == FM / 2 + FM / 4) bs[1] = rdB(nslot, FN - 1);
-          }
-          if (k >= 1 && i == 0) b[2 * k - 2] = rdB(nslot, 2 * k - 2);
-          if (k >= 1 && i == 1) b[2 * k - 1] = rdB(nslot, 2 * k - 1);
+      for (int i = 0; i < FM; ++i) a[i] = rdA(slot, i);
+      slot = slot + 1 == NSLOT ? 0 : slot + 1;
+#pragma unroll
+      for (int k = 0; k < FN / 2; ++k) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          mma<T>(b[2 * k], a[i], acc[2 * k][i]);
+          mma<T>(b[2 * k + 1], a[i], acc[2 * k + 1][i]);
         }
       }
-      if (k == 0 && do_issue) {
-#pragma unroll
-        for (int q = FM; q < L; ++q) issue_piece(q);   // (only when a lane has more DMA pieces than row fragments)
-      }
-    }
-    if (p.debug & 16) __builtin_amdgcn_s_setprio(0);
-    if (do_issue) { end_issue(); ++issued; }
-    if (roll) { b[FN - 2] = bs[0]; b[FN - 1] = bs[1]; }
-    ++c_kt;
-    if (stamp) { SR_STAMP(t1); tm_ += t1 - t0; t0 = t1; }
-    if (tile_end) {
-      epilogue(c_tile);
-      stored = !p.no_store;
-      c_kt = 0;
-      c_tile += G;
-      clear_acc();
-      if (has_next) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i) a[i] = rdA(nslot, i);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) b[j] = rdB(nslot, j);
-      }
-      if (stamp) { SR_STAMP(t1); te += t1 - t0; }
-    }
-  }
-  if (stamp && blockIdx.x < 256 && (threadIdx.x & 63) == 0) {
-    unsigned long long* o = g_stamps + ((blockIdx.x * 8 + wave) & 2047) * 8;
-    o[0] = tw; o[1] = tb; o[2] = 0; o[3] = tm_; o[4] = te; o[5] = (unsigned long long)total;
 #ifdef SR_STAMPS
-    o[2] = te_prep; o[6] = te_stats; o[7] = te_store;
+      if (stamp) { SR_STAMP(t1); tm_ += t1 - t0; t0 = t1; }
 #endif
+      if (--c_left == 0) {
+        epilogue(c_tile);
+        since_epi = p.no_store ? 0 : D;
+        c_left = nkt;
+        c_tile += G;
+        clear_acc();
+#ifdef SR_STAMPS
+        if (stamp) { SR_STAMP(t1); te += t1 - t0; }
+#endif
+      }
+    }
+#ifdef SR_STAMPS
+    if (stamp && blockIdx.x < 256 && (threadIdx.x & 63) == 0) {
+      unsigned long long* o = g_stamps + ((blockIdx.x * 8 + wave) & 2047) * 8;
+      o[0] = tw; o[1] = tb; o[3] = tm_; o[4] = te; o[5] = (unsigned long long)total;
+      o[2] = te_prep; o[6] = te_stats; o[7] = te_store;
+    }
+#endif
+    return;
   }
+
 }
 
 constexpr int v3_threads(int CFG) { return (CFG == 1 || CFG == 8) ? 256 : 128 * CFG; }
