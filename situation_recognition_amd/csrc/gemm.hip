@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -876,9 +877,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         st_aoff = st_woff;
       }
     };
-    auto advance = [&]() {
-      ++ld_kt;
-      if (--seg_left > 0) { st_aoff += STEPB; st_woff += STEPB; return; }
+    auto advance_tail = [&]() {                  // the segment ended: next tap / operand pair / tile
       if (ld_kt == nkt) {
         ld_kt = 0; ld_pr = 0; ld_k0 = 0;
         ld_tile += G;
@@ -889,6 +888,11 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         setup_ptrs(ld_tile, ld_pr);
       }
       refresh();
+    };
+    auto advance = [&]() {
+      ++ld_kt;
+      if (--seg_left > 0) { st_aoff += STEPB; st_woff += STEPB; return; }
+      advance_tail();
     };
     auto issue_step = [&](int slot) {
       st_slot = slot;
@@ -916,50 +920,175 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
 #endif
     Frag<T> a[FM], b[FN];
     int slot = 0, islot = D % NSLOT;
-    for (int s = 0; s < total; ++s) {
-#ifdef SR_STAMPS
-      if (stamp) SR_STAMP(t0);
-#endif
-      if (since_epi == 0 && issued - s == D && D == 3) wait_vm<2 * L>();
-      else if (since_epi == 0 && issued - s == D && D == 2) wait_vm<L>();
-      else slow_wait(issued - s - 1);
-#ifdef SR_STAMPS
-      if (stamp) { SR_STAMP(t1); tw += t1 - t0; }
-#endif
-      __builtin_amdgcn_s_barrier();
-#ifdef SR_STAMPS
-      if (stamp) { SR_STAMP(t0); tb += t0 - t1; }
-#endif
-      if (issued < total) {
-        issue_step(islot);
-        ++issued;
-        islot = islot + 1 == NSLOT ? 0 : islot + 1;
+    if (CFG == 4 && !(p.debug & 32)) {
+      // ---- 256x256 tile, 8 waves: the two wave groups (wm = 0 / 1: one wave of each per SIMD) run HALF A STEP apart.
+      // A step is an L section (12 fragment reads, the 4 DMA pieces of step s+3, wait for the reads) and an M section
+      // (32 back-to-back MFMAs at raised priority, no memory instruction), each closed by a barrier; group 1 starts one
+      // barrier late, so while one wave of a SIMD multiplies the other one loads.  Skeleton of this schedule
+      // (tools/ubench/dma_shapes.hip): 1265 cycles per step against 1735 for the lock-step form.
+      // Barrier instances pair as G0.B1(s) = G1.B2(s-1), G0.B2(s) = G1.B1(s).
+      //   read-after-DMA : step s is read in L(s); every wave has waited for its own pieces of step s before the last
+      //                    instance both groups pass ahead of that (G0: end of M(s-1), before B2(s-1); G1: in L(s-1), before B1(s-1)).
+      //   DMA-after-read : the pieces of step s+3 overwrite the slot of step s-1, whose reads both groups drained
+      //                    (lgkmcnt 0) before their B1(s-1) -- an instance both have passed when L(s) starts.
+      // At a tile end group 0 takes one extra barrier (the groups re-align and run the epilogue together; otherwise the
+      // two epilogues would serialise), then group 1 takes one to fall half a step behind again.
+      {
+        const int later = issued - 1;
+        if (later >= 2) wait_vm<2 * L>(); else if (later == 1) wait_vm<L>(); else wait_vm<0>();
       }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (wm == 1) __builtin_amdgcn_s_barrier();
+      auto wait_next = [&](int s) {          // my pieces of step s+1 (called after the pieces of step s+D were issued)
+        if (since_epi == 0 && issued - s == D + 1) { wait_vm<2 * L>(); return; }
+        const bool st = since_epi > 0 && !two && S > 0;
+        if (since_epi > 0) --since_epi;
+        if (s + 1 >= total) return;
+        const int later = issued - s - 2;
+        if (st) {
+          if (later >= 2) wait_vm<2 * L + S>(); else if (later == 1) wait_vm<L + S>(); else wait_vm<S>();
+        } else {
+          if (later >= 2) wait_vm<2 * L>(); else if (later == 1) wait_vm<L>(); else wait_vm<0>();
+        }
+      };
+      // Runs of steps are an inner loop that never redefines the loader's registers: a segment change (next tap /
+      // operand pair / tile: setup_ptrs) happens BETWEEN runs, as does the epilogue.  With that slow path inside the step,
+      // hipcc copied ~25 loop-carried registers per step; two copies of the step body (steady / generic) made it spill.
+      auto pp_step = [&](bool steady, int s) {
+#ifdef SR_STAMPS
+        if (stamp) SR_STAMP(t0);
+#endif
 #pragma unroll
-      for (int j = 0; j < FN; ++j) b[j] = rdB(slot, j);
+        for (int j = 0; j < FN; ++j) b[j] = rdB(slot, j);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) a[i] = rdA(slot, i);
-      slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        for (int i = 0; i < FM; ++i) a[i] = rdA(slot, i);
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        if (issued < total) {
+          st_slot = islot;
 #pragma unroll
-      for (int k = 0; k < FN / 2; ++k) {
+          for (int q = 0; q < L; ++q) issue_piece(q);
+          ++ld_kt; --seg_left; st_aoff += STEPB; st_woff += STEPB;
+          ++issued;
+          islot = islot + 1 == NSLOT ? 0 : islot + 1;
+        }
+        if (wm == 1) { if (steady) wait_vm<2 * L>(); else wait_next(s); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef SR_STAMPS
+        if (stamp) { SR_STAMP(t1); tw += t1 - t0; }
+#endif
+        __builtin_amdgcn_s_barrier();                    // B1
+#ifdef SR_STAMPS
+        if (stamp) { SR_STAMP(t0); tb += t0 - t1; }
+#endif
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          mma<T>(b[2 * k], a[i], acc[2 * k][i]);
-          mma<T>(b[2 * k + 1], a[i], acc[2 * k + 1][i]);
+        for (int k = 0; k < FN / 2; ++k) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            mma<T>(b[2 * k], a[i], acc[2 * k][i]);
+            mma<T>(b[2 * k + 1], a[i], acc[2 * k + 1][i]);
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (wm == 0) { if (steady) wait_vm<2 * L>(); else wait_next(s); }
+#ifdef SR_STAMPS
+        if (stamp) { SR_STAMP(t1); tm_ += t1 - t0; }
+#endif
+        __builtin_amdgcn_s_barrier();                    // B2
+#ifdef SR_STAMPS
+        if (stamp) { SR_STAMP(t0); tb += t0 - t1; }
+#endif
+      };
+      int s = 0;
+      while (s < total) {
+        const bool steady = since_epi == 0 && issued - s == D && issued < total;   // (n >= 1 below: all three terms are)
+        int n = 1;
+        if (steady) {
+          n = total - issued;
+          n = c_left < n ? c_left : n;
+          n = seg_left < n ? seg_left : n;
+        }
+        for (int i = 0; i < n; ++i) pp_step(steady, s + i);
+        s += n;
+        c_left -= n;
+        if (seg_left == 0) advance_tail();
+        if (c_left == 0) {
+          if (wm == 0) __builtin_amdgcn_s_barrier();     // re-align
+          epilogue(c_tile);
+          since_epi = p.no_store ? 0 : D - 1;
+          c_left = nkt;
+          c_tile += G;
+          clear_acc();
+          if (wm == 1 && s < total) __builtin_amdgcn_s_barrier();   // fall half a step behind again
+#ifdef SR_STAMPS
+          if (stamp) { SR_STAMP(t1); te += t1 - t0; }
+#endif
         }
       }
+    } else {
+      // ---- 4-wave tiles (two workgroups per CU): lock-step form of the same step; runs of steps as above
+      auto plain_step = [&](bool steady, int s) {
 #ifdef SR_STAMPS
-      if (stamp) { SR_STAMP(t1); tm_ += t1 - t0; t0 = t1; }
+        if (stamp) SR_STAMP(t0);
 #endif
-      if (--c_left == 0) {
-        epilogue(c_tile);
-        since_epi = p.no_store ? 0 : D;
-        c_left = nkt;
-        c_tile += G;
-        clear_acc();
+        if (steady) { if (D == 3) wait_vm<2 * L>(); else wait_vm<L>(); }
+        else slow_wait(issued - s - 1);
 #ifdef SR_STAMPS
-        if (stamp) { SR_STAMP(t1); te += t1 - t0; }
+        if (stamp) { SR_STAMP(t1); tw += t1 - t0; }
 #endif
+        __builtin_amdgcn_s_barrier();
+#ifdef SR_STAMPS
+        if (stamp) { SR_STAMP(t0); tb += t0 - t1; }
+#endif
+        if (issued < total) {
+          st_slot = islot;
+#pragma unroll
+          for (int q = 0; q < L; ++q) issue_piece(q);
+          ++ld_kt; --seg_left; st_aoff += STEPB; st_woff += STEPB;
+          ++issued;
+          islot = islot + 1 == NSLOT ? 0 : islot + 1;
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = rdB(slot, j);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = rdA(slot, i);
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+#pragma unroll
+        for (int k = 0; k < FN / 2; ++k) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            mma<T>(b[2 * k], a[i], acc[2 * k][i]);
+            mma<T>(b[2 * k + 1], a[i], acc[2 * k + 1][i]);
+          }
+        }
+#ifdef SR_STAMPS
+        if (stamp) { SR_STAMP(t1); tm_ += t1 - t0; t0 = t1; }
+#endif
+      };
+      int s = 0;
+      while (s < total) {
+        const bool steady = since_epi == 0 && issued - s == D && issued < total;   // (n >= 1 below: all three terms are)
+        int n = 1;
+        if (steady) {
+          n = total - issued;
+          n = c_left < n ? c_left : n;
+          n = seg_left < n ? seg_left : n;
+        }
+        for (int i = 0; i < n; ++i) plain_step(steady, s + i);
+        s += n;
+        c_left -= n;
+        if (seg_left == 0) advance_tail();
+        if (c_left == 0) {
+          epilogue(c_tile);
+          since_epi = p.no_store ? 0 : D;
+          c_left = nkt;
+          c_tile += G;
+          clear_acc();
+#ifdef SR_STAMPS
+          if (stamp) { SR_STAMP(t1); te += t1 - t0; }
+#endif
+        }
       }
     }
 #ifdef SR_STAMPS

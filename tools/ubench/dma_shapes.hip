@@ -45,6 +45,38 @@ __global__ __launch_bounds__(512, 1) void k(const char* src, long ld, int steps,
   };
   issue(0); issue(1); issue(2);
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (READS == 3) {
+    // ping-pong: waves 4-7 run one barrier behind waves 0-3; L = reads + DMA issue + wait for the reads, M = 32 MFMAs
+    const int grp = wave >> 2;
+    wait_vm<8>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < steps; ++s) {
+      const char* slot = smem + (s & 3) * 32768;
+      const int off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane & 8) >> 2)) << 4);
+      bf16x8_t a[8], b[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(slot + (wave >> 2) * 8192 + i * 1024 + off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(slot + 16384 + (wave & 3) * 4096 + j * 1024 + off);
+      issue(s + 3);
+      if (grp == 1) wait_vm<8>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2 * j], a[i], acc[i], 0, 0, 0);
+          acc[8 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2 * j + 1], a[i], acc[8 + i], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+      if (grp == 0) wait_vm<8>();
+      __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else
   for (int s = 0; s < steps; ++s) {
     wait_vm<8>();
     __builtin_amdgcn_s_barrier();
@@ -123,6 +155,7 @@ int main(int argc, char** argv) {
     run<0, 2>(src, ld, "16 rows x  64 B"); run<1, 2>(src, ld, " 8 rows x 128 B"); run<2, 2>(src, ld, " 4 rows x 256 B");
     run<0, 2, 1>(src, ld, "16 rows x  64 B"); run<1, 2, 1>(src, ld, " 8 rows x 128 B");
     run<0, 2, 2>(src, ld, "16 rows x  64 B"); run<1, 2, 2>(src, ld, " 8 rows x 128 B");
+    run<0, 2, 3>(src, ld, "16x64 ping-pong"); run<1, 2, 3>(src, ld, "8x128 ping-pong");
     run<0, 2, 1, 15>(src, ld, "16 rows x  64 B"); run<0, 2, 1, 30>(src, ld, "16 rows x  64 B"); run<0, 2, 1, 60>(src, ld, "16 rows x  64 B");
   }
   return 0;
