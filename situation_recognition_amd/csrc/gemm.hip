@@ -632,17 +632,26 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[j][r] = (p.bias ? p.bias_scale * b1[j][r] : 0.f) + (p.bias2 ? b2[j][r] : 0.f);
     }
+    // per-column multiplier: applied as one FMA with the bias in the store pass (a statistics pass, which needs the
+    // scaled values themselves, folds it into the accumulators first)
     const bool scaled = p.escale != nullptr;
-    if (scaled) {  // fold the multiplier into the accumulators once (registers: none extra)
-      float ev[FN][4];
+    float ev[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ev[j][r] = 1.f;
+    if (scaled) {
       colvec(p.escale, ev);
+      if (want_stats) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+          for (int r = 0; r < 4; ++r) {
 #pragma unroll
-          for (int i = 0; i < FM; ++i) acc[j][i][r] *= ev[j][r];
-        }
+            for (int i = 0; i < FM; ++i) acc[j][i][r] *= ev[j][r];
+            ev[j][r] = 1.f;
+          }
+      }
     }
 #ifdef SR_STAMPS
     if (estamp) { SR_STAMP(te1); te_prep += te1 - te0; te0 = te1; }
@@ -742,7 +751,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         const bool ok = (m < p.M) && (n < Nv);
         float v[4], o2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] + bv[j][r];
+        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[j][i][r], ev[j][r], bv[j][r]);
         if (p.res && !rowres) {
           float rv[4];
           load4<TO>(ok ? (const TO*)p.res + m * p.ldres + n : zeros, rv);

@@ -234,7 +234,8 @@ class resnet(nn.Module):
             # cheap GEMM and applies scale/shift (+identity, ReLU) in its epilogue.  HBM traffic per output element drops
             # from 5 accesses (write raw, read raw, read identity, write) to 2 (read identity, write).
             Ho, Wo = (x.shape[1] - 1) // u.stride + 1, (x.shape[2] - 1) // u.stride + 1
-            if self.gram_stats and dt == torch.bfloat16 and u.stride == 1 and u.cin_p in (64, 128, 256, 512) and u.cout_p >= 4 * u.cin_p:
+            if (self.gram_stats and dt == torch.bfloat16 and u.stride == 1 and u.cin_p in (64, 128, 256, 512) and u.cout_p >= 4 * u.cin_p
+                    and x.shape[0] * Ho * Wo >= 256 * u.cin_p):   # (below ~256*C pixels the fixed cost of the fp64 finalize loses to launch 1)
                 # Expansion conv (N = 4C): its batch statistics follow from the C x C Gram matrix of the input
                 # (sum y^2 = w G w^T), a quarter of the conv's MFMA work and one read of x -- no launch 1 at all.
                 part = ops.gram(x.view(-1, u.cin_p))

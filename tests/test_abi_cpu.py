@@ -47,7 +47,8 @@ def test_argument_validation_needs_no_gpu(libpath):
 
 def test_gram_plan_needs_no_gpu(libpath):
     """Row slices of the Gram statistics kernel: one per CU (256 assumed without a device), split further so that no
-    fp32 accumulator sums more than 8192 pixels; 64/128-wide inputs write 4/2 k-split partials per slice."""
+    fp32 accumulator sums more than 8192 pixels; 64/128-wide inputs write 4/2 k-split partials per slice.
+    (Fewer, longer slices to save partial traffic were measured slower at every size: the kernel wants all CUs.)"""
     from situation_recognition_amd import _lib
     l = _lib.lib()
     n, f = ctypes.c_int64(), ctypes.c_int64()
