@@ -87,3 +87,42 @@ def test_config3_resnet152_bf16_slicing_and_train_invariants():
     assert not torch.equal(rv0, net.convnet_verbs.model.layer3[5].bn2.running_var)
     assert int(net.state_dict()["convnet_nouns.model.bn1.num_batches_tracked"]) == 2        # two passes' worth (model.py:176-178)
     assert int(net.state_dict()["convnet_verbs.model.bn1.num_batches_tracked"]) == 1
+
+
+def test_gram_statistics_route_matches_statistics_only_launch_in_the_backbone():
+    """Train-mode ResNet-50 pass (bf16, batch 352: the expansion convs of layers 1-3 are above the 256*C-pixel threshold
+    and take the Gram route, layer4 the statistics-only launch).  At every expansion conv that takes the Gram route the
+    scale/shift it produces are compared IN SITU with the ones a statistics-only launch of the conv gives on the same
+    input (end-to-end features are not compared: 50 bf16 layers of batch-normalised random weights amplify one-ulp
+    differences to several percent)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from situation_recognition_amd import ops
+    from situation_recognition_amd.model import resnet
+    torch.manual_seed(3)
+    net = resnet(None, depth=50, dtype=torch.bfloat16).cuda().train()
+    img = torch.randn(352, 3, 224, 224, device="cuda").clamp_(-2.2, 2.7)
+    seen, last_x = [], {}
+    gram0, fin0 = ops.gram, ops.bn_finalize_gram
+
+    def gram(x2d):
+        last_x["x"] = x2d
+        return gram0(x2d)
+
+    def fin(part, w, count, gamma, beta, rm, rv, momentum, eps):
+        scale, shift = fin0(part, w, count, gamma, beta, rm, rv, momentum, eps)
+        x2d = last_x["x"]
+        st = ops.conv2d(x2d.view(1, x2d.shape[0], 1, x2d.shape[1]), w.reshape(w.shape[0], -1), w.shape[0], 1, 1, 0, stats_only=True)
+        s2, h2 = ops.bn_finalize(st, count, gamma, beta, None, None, momentum, eps)
+        seen.append((w.shape[1], float(((scale - s2).abs() / s2.abs().clamp_min(1e-3)).max()), float((shift - h2).abs().max())))
+        return scale, shift
+
+    ops.gram, ops.bn_finalize_gram = gram, fin
+    try:
+        f = net(img)
+    finally:
+        ops.gram, ops.bn_finalize_gram = gram0, fin0
+    assert torch.isfinite(f).all()
+    assert sorted(set(c for c, _, _ in seen)) == [64, 128, 256] and len(seen) == (3 + 1) + 4 + 6   # (+1: layer1's stride-1 downsample)
+    for c, ds, dh in seen:
+        assert ds < 5e-5 and dh < 5e-4, (c, ds, dh)
