@@ -451,11 +451,14 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   constexpr int WAVES_M = CFG == 1 ? 4 : 2, FM = 16 / WAVES_M;          // FM: 16-row fragments per wave along M
   constexpr int BM = 256, BN = 16 * FN * WAVES_N, NW = WAVES_M * WAVES_N;
   constexpr int EPC = 16 / (int)sizeof(T), BK = 4 * EPC;
-  constexpr int NSLOT = (CFG == 4 || CFG == 8) ? 4 : 3;
+  // ring slots.  256x256: FIVE slots of 32 KiB = the whole 160 KiB; the epilogue's staging strips live in the slot the
+  // tile's last step was read from (free until the next step's DMA, which waits behind a barrier after the epilogue).
+  constexpr int NSLOT = CFG == 4 ? 5 : (CFG == 8 ? 4 : 3);
   constexpr int CPR = 2 * FN;          // 16-byte chunks per row of the per-wave output strip
   constexpr int RPI = 64 / CPR;        // strip rows moved by one wave-instruction
   constexpr int NH = 16 / RPI;         // instructions per 16-row strip
-  constexpr int SLOT = (BM + BN) * 64, STG_OFF = NSLOT * SLOT;
+  constexpr int SLOT = (BM + BN) * 64, STG_OFF = CFG == 4 ? 0 : NSLOT * SLOT;
+  int stg_off = STG_OFF;
   constexpr int A_PER = (BM / 16) / NW, B_PER = (BN / 16) / NW;
   constexpr int L = A_PER + B_PER;                      // DMA instructions per lane per step
   constexpr bool STAGED = sizeof(TO) == 2;              // 16-bit outputs leave through a per-wave LDS staging strip
@@ -744,7 +747,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
       for (int h = 0; h < NH; ++h) rcur[h] = rowres ? rall[i % RD][h] : make_uint4(0, 0, 0, 0);
       if (rowres && i + RD < FM) fetch_res(i + RD, rall[i % RD]);
       const long m = m0 + wm * FM * 16 + i * 16 + frow;
-      char* stg = smem + STG_OFF + wave * (16 * CPR * 16);  // per-wave [16 rows][16*FN cols] 16-bit strip; 16-B chunk c of row r at c ^ (r & (CPR-1))
+      char* stg = smem + stg_off + wave * (16 * CPR * 16);  // per-wave [16 rows][16*FN cols] 16-bit strip; 16-B chunk c of row r at c ^ (r & (CPR-1))
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int n = n0 + wn * FN * 16 + j * 16 + fgrp * 4;
@@ -942,24 +945,23 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
       //                    (lgkmcnt 0) before their B1(s-1) -- an instance both have passed when L(s) starts.
       // At a tile end group 0 takes one extra barrier (the groups re-align and run the epilogue together; otherwise the
       // two epilogues would serialise), then group 1 takes one to fall half a step behind again.
-      {
-        const int later = issued - 1;
-        if (later >= 2) wait_vm<2 * L>(); else if (later == 1) wait_vm<L>(); else wait_vm<0>();
-      }
+      static_assert((D - 1) * L + S < 64 && D <= 4, "vmcnt is a 6-bit counter");
+      auto wait_later = [&](int later, bool st) {   // all but the `later` youngest DMA groups (+ an epilogue's S stores)
+        if (st) {
+          if (later >= 3) wait_vm<3 * L + S>(); else if (later == 2) wait_vm<2 * L + S>(); else if (later == 1) wait_vm<L + S>(); else wait_vm<S>();
+        } else {
+          if (later >= 3) wait_vm<3 * L>(); else if (later == 2) wait_vm<2 * L>(); else if (later == 1) wait_vm<L>(); else wait_vm<0>();
+        }
+      };
+      wait_later(issued - 1, false);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (wm == 1) __builtin_amdgcn_s_barrier();
       auto wait_next = [&](int s) {          // my pieces of step s+1 (called after the pieces of step s+D were issued)
-        if (since_epi == 0 && issued - s == D + 1) { wait_vm<2 * L>(); return; }
         const bool st = since_epi > 0 && !two && S > 0;
         if (since_epi > 0) --since_epi;
         if (s + 1 >= total) return;
-        const int later = issued - s - 2;
-        if (st) {
-          if (later >= 2) wait_vm<2 * L + S>(); else if (later == 1) wait_vm<L + S>(); else wait_vm<S>();
-        } else {
-          if (later >= 2) wait_vm<2 * L>(); else if (later == 1) wait_vm<L>(); else wait_vm<0>();
-        }
+        wait_later(issued - s - 2, st);
       };
       // Runs of steps are an inner loop that never redefines the loader's registers: a segment change (next tap /
       // operand pair / tile: setup_ptrs) happens BETWEEN runs, as does the epilogue.  With that slow path inside the step,
@@ -981,7 +983,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
           ++issued;
           islot = islot + 1 == NSLOT ? 0 : islot + 1;
         }
-        if (wm == 1) { if (steady) wait_vm<2 * L>(); else wait_next(s); }
+        if (wm == 1) { if (steady) wait_vm<(D - 1) * L>(); else wait_next(s); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef SR_STAMPS
         if (stamp) { SR_STAMP(t1); tw += t1 - t0; }
@@ -1000,7 +1002,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
           }
         }
         __builtin_amdgcn_s_setprio(0);
-        if (wm == 0) { if (steady) wait_vm<2 * L>(); else wait_next(s); }
+        if (wm == 0) { if (steady) wait_vm<(D - 1) * L>(); else wait_next(s); }
 #ifdef SR_STAMPS
         if (stamp) { SR_STAMP(t1); tm_ += t1 - t0; }
 #endif
@@ -1024,12 +1026,17 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         if (seg_left == 0) advance_tail();
         if (c_left == 0) {
           if (wm == 0) __builtin_amdgcn_s_barrier();     // re-align
+          stg_off = (slot == 0 ? NSLOT - 1 : slot - 1) * SLOT;   // the slot of the step just consumed: free until the next DMA
           epilogue(c_tile);
           since_epi = p.no_store ? 0 : D - 1;
           c_left = nkt;
           c_tile += G;
           clear_acc();
-          if (wm == 1 && s < total) __builtin_amdgcn_s_barrier();   // fall half a step behind again
+          if (s < total) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                // every wave is done with its staging strip: the slot may be refilled
+            if (wm == 1) __builtin_amdgcn_s_barrier();   // fall half a step behind again
+          }
 #ifdef SR_STAMPS
           if (stamp) { SR_STAMP(t1); te += t1 - t0; }
 #endif
@@ -1191,7 +1198,7 @@ int launch_v3(const KArgs& k_in, hipStream_t st) {
   constexpr int WG_PER_CU = (WN == 4 || WN == 8) ? 1 : 2;
   const long gm = ((long)k.M + 255) / 256, gn = (k.N + BN - 1) / BN;
   if (gm * gn > 0x7fffffffL) return SR_ERR_ARG;
-  const size_t lds = NSLOT * (256 + BN) * 64 + (NTHR / 64) * (WN == 8 ? 4096 : 2048);
+  const size_t lds = WN == 4 ? (size_t)5 * (256 + BN) * 64 : NSLOT * (256 + BN) * 64 + (NTHR / 64) * (WN == 8 ? 4096 : 2048);
   const long ntiles = gm * gn, cap = (long)num_cus() * WG_PER_CU;
   const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
   int rc = SR_OK;
