@@ -22,6 +22,8 @@ namespace {
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
+constexpr int SR_STATS_FLUSH = 32;   // tiles a workgroup accumulates BatchNorm partial sums over before reducing + storing them
+
 struct ConvGeom {
   int on, H, Wd, Ho, Wo, stride, pad, KW, lgCseg, cpix;
 };
@@ -39,6 +41,7 @@ struct KArgs {
   ConvGeom cv;
   const float* escale;    // optional per-column multiplier applied to the accumulator before the bias (v3 kernels only)
   int no_store;           // statistics-only launch: the tile is not written (v3 kernels only)
+  int stats_nflush;       // partial-statistics rows each workgroup writes (v3 kernels; see SR_STATS_FLUSH)
   const void* zero_page;  // 256 zero bytes (device address of g_zero_page, resolved once on the host)
   void* trash_page;       // sink for out-of-range lanes' stores
   int debug;  // SR_GEMM_DEBUG bits (diagnostic builds of bench scripts only): 1 = skip MFMA, 2 = skip loads after the prologue
@@ -594,6 +597,47 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   const int Nv = (p.N + 3) & ~3;
   const TO* const zeros = reinterpret_cast<const TO*>(p.zero_page);
 
+  // BatchNorm partial sums: every tile of this workgroup covers the same columns (the host makes the grid a multiple of
+  // the column-tile count), so each lane keeps RUNNING per-column sums over its tiles and the 16-lane reduction + store
+  // happens once per SR_STATS_FLUSH tiles, not once per tile (it was 4-5 K cycles of DPP chains per tile; the partial
+  // buffer shrinks by the same factor: the stem's was 616 MB).  Row of flush f: ((vb / gn) * nflush + f) * WAVES_M + wm.
+  constexpr bool STATS_OK = EPI == 0;
+  constexpr int RSN = STATS_OK ? FN : 1;
+  float rs1[RSN][4], rs2[RSN][4];
+#pragma unroll
+  for (int j = 0; j < RSN; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs1[j][r] = rs2[j][r] = 0.f;
+  int st_cnt = 0, st_flush = 0;
+  auto stats_flush = [&](bool zero) {
+    const int el = fresh_lane();
+    const int frow = el & 15, fgrp = el >> 4;
+    const int n0 = (vb % gn) * BN;
+    float* row = p.stats + ((long)((vb / gn) * p.stats_nflush + st_flush) * WAVES_M + wm) * 2 * p.N;
+#pragma unroll
+    for (int j = 0; j < RSN; ++j) {
+      const int nj = n0 + wn * FN * 16 + j * 16 + fgrp * 4;
+      float s1[4], s2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s1[r] = zero ? 0.f : row16_sum(rs1[j][r]);
+        s2[r] = zero ? 0.f : row16_sum(rs2[j][r]);
+        rs1[j][r] = 0.f; rs2[j][r] = 0.f;
+      }
+      if (frow == 0) {
+        if (nj + 3 < p.N && (p.N & 3) == 0) {
+          *reinterpret_cast<float4*>(row + nj) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+          *reinterpret_cast<float4*>(row + p.N + nj) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nj + r < p.N) { row[nj + r] = s1[r]; row[p.N + nj + r] = s2[r]; }
+        }
+      }
+    }
+    ++st_flush;
+    st_cnt = 0;
+  };
 #ifdef SR_STAMPS
   unsigned long long te_prep = 0, te_stats = 0, te_store = 0, te0 = 0, te1 = 0;
   const bool estamp = (p.debug & 4) != 0;
@@ -605,7 +649,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     const int tm = tile / gn, tn = tile - tm * gn;
     const long m0 = (long)tm * BM;
     const int n0 = tn * BN;
-    const bool want_stats = p.stats != nullptr;
+    const bool want_stats = STATS_OK && p.stats != nullptr;
     const int el = fresh_lane();
     const int frow = el & 15, fgrp = el >> 4;
     TO* const trash = reinterpret_cast<TO*>((char*)p.trash_page + el * 16);
@@ -697,19 +741,13 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
             }
           }
         }
+        if constexpr (STATS_OK) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
-        if (frow == 0) {
-          float* row = p.stats + ((long)(tm * WAVES_M + wm) * 2) * p.N;
-          if (nj + 3 < p.N && (p.N & 3) == 0) {
-            *reinterpret_cast<float4*>(row + nj) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-            *reinterpret_cast<float4*>(row + p.N + nj) = make_float4(s2[0], s2[1], s2[2], s2[3]);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (nj + r < p.N) { row[nj + r] = s1[r]; row[p.N + nj + r] = s2[r]; }
-          }
+          for (int r = 0; r < 4; ++r) { rs1[j][r] += s1[r]; rs2[j][r] += s2[r]; }
         }
+      }
+      if constexpr (STATS_OK) {
+        if (++st_cnt == SR_STATS_FLUSH || tile + G >= ntiles) stats_flush(false);
       }
     }
 #ifdef SR_STAMPS
@@ -1107,6 +1145,11 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         }
       }
     }
+    if constexpr (STATS_OK) {
+      if (p.stats) {
+        while (st_flush < p.stats_nflush) stats_flush(true);   // the rows of flushes this workgroup never reached: zeros
+      }
+    }
 #ifdef SR_STAMPS
     if (stamp && blockIdx.x < 256 && (threadIdx.x & 63) == 0) {
       unsigned long long* o = g_stamps + ((blockIdx.x * 8 + wave) & 2047) * 8;
@@ -1190,17 +1233,33 @@ int launch_v3e(const KArgs& k, unsigned grid, size_t lds, hipStream_t st) {
   return SR_OK;
 }
 
+// Grid and partial-statistics layout of a v3 launch (shared by the launcher and sr_gemm_stats_tiles): with statistics
+// the grid is a multiple of the column-tile count gn, so that a workgroup's tiles all cover the same columns.
+struct V3Plan { long grid, gn, nflush, rows; };
+inline V3Plan v3_plan(long M, int N, int cfg, bool stats) {
+  const int BN = 64 * cfg, wg_per_cu = cfg == 4 ? 1 : 2, waves_m = cfg == 1 ? 4 : 2;
+  const long gm = (M + 255) / 256, gn = (N + BN - 1) / BN, ntiles = gm * gn, cap = (long)num_cus() * wg_per_cu;
+  V3Plan pl{ntiles < cap ? ntiles : cap, gn, 0, 0};
+  if (stats) {
+    if (pl.grid >= gn) pl.grid -= pl.grid % gn; else pl.grid = gn;
+    const long groups = pl.grid / gn, per_wg = (gm + groups - 1) / groups;
+    pl.nflush = (per_wg + SR_STATS_FLUSH - 1) / SR_STATS_FLUSH;
+    pl.rows = groups * pl.nflush * waves_m;
+  }
+  return pl;
+}
+
 template <typename T, typename TO, int WN>
 int launch_v3(const KArgs& k_in, hipStream_t st) {
   KArgs k = k_in;
   for (int i = 0; i < 3; ++i) k.nk[i] *= 2;  // host counts 128-byte K-tiles; v3 steps are 64 bytes
   constexpr int BN = WN == 8 ? 256 : 64 * WN, NSLOT = (WN == 4 || WN == 8) ? 4 : 3, NTHR = v3_threads(WN);
-  constexpr int WG_PER_CU = (WN == 4 || WN == 8) ? 1 : 2;
   const long gm = ((long)k.M + 255) / 256, gn = (k.N + BN - 1) / BN;
   if (gm * gn > 0x7fffffffL) return SR_ERR_ARG;
   const size_t lds = WN == 4 ? (size_t)5 * (256 + BN) * 64 : NSLOT * (256 + BN) * 64 + (NTHR / 64) * (WN == 8 ? 4096 : 2048);
-  const long ntiles = gm * gn, cap = (long)num_cus() * WG_PER_CU;
-  const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+  const V3Plan pl = v3_plan(k.M, k.N, WN, k.stats != nullptr);
+  k.stats_nflush = (int)pl.nflush;
+  const unsigned grid = (unsigned)pl.grid;
   int rc = SR_OK;
   if (k.cv.on) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v3_kernel<T, TO, WN>),
@@ -1303,11 +1362,11 @@ extern "C" int sr_debug_stamps(unsigned long long* host_out, int count) {
 
 extern "C" int sr_gemm_stats_tiles(int M, int N) {
   const int gm = (M + 255) / 256;
-  switch (v3_cfg(M, N, true)) {          // statistics are only produced with a linear epilogue
-    case 4: case 2: return 2 * gm;       // one partial row per 128-row wave group
-    case 1: return 4 * gm;               // four 64-row wave groups per tile
-    default: return gm;                  // v2: one row per 256-row tile
-  }
+  const int cfg = v3_cfg(M, N, true);    // statistics are only produced with a linear epilogue
+  if (cfg == 0) return gm;               // v2: one row per 256-row tile
+  // v3: one row per (workgroup column-tile group, flush, wave group): each workgroup keeps running sums over up to
+  // SR_STATS_FLUSH of its tiles (all of which cover the same columns)
+  return (int)v3_plan(M, N, cfg, true).rows;
 }
 
 extern "C" int sr_gemm(const sr_gemm_args* a, int dtype, void* stream) {

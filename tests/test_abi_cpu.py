@@ -36,13 +36,14 @@ def test_argument_validation_needs_no_gpu(libpath):
     a.npairs, a.M, a.N = 1, 4, 4
     assert l.sr_gemm(ctypes.byref(a), 7, None) in (-1, -2)
     assert l.sr_conv2d(None, 1, None) == -1
-    # partial-statistics rows follow the tile shape the kernel will pick for (M, N): 256x64 tiles -> 4 rows per 256 rows,
-    # 256x128 / 256x256 -> 2; small problems are given the narrow shapes so that more workgroups exist
+    # partial-statistics rows: one per (workgroup group, flush of up to 32 tiles, wave group of the tile shape the kernel
+    # will pick for (M, N): 4 wave groups for 256x64 tiles, 2 for 256x128 / 256x256); 256 CUs assumed without a device
     assert l.sr_gemm_stats_tiles(1000, 64) == 16
     assert l.sr_gemm_stats_tiles(1000, 128) == 8
     assert l.sr_gemm_stats_tiles(1000, 256) == 16
-    assert l.sr_gemm_stats_tiles(1204224, 256) == 2 * 4704
-    assert l.sr_gemm_stats_tiles(1204224, 64) == 4 * 4704
+    assert l.sr_gemm_stats_tiles(1204224, 256) == 256 * 2          # 256 workgroups x 19 tiles each: one flush
+    assert l.sr_gemm_stats_tiles(1204224, 64) == 512 * 4
+    assert l.sr_gemm_stats_tiles(19267584, 64) == 512 * 5 * 4      # 147 tiles per workgroup: five flushes
 
 
 def test_gram_plan_needs_no_gpu(libpath):
