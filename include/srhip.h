@@ -59,9 +59,10 @@ typedef struct sr_kpair {
  * of the classifiers (model.py:152,168) and, in backward, their autograd GEMMs.
  * Up to 3 operand pairs are summed into one accumulator (W_z n + U_z h in one launch).
  * out_f32 != 0: C / C2 / res / aux are fp32 even when dtype is bf16.
- * stats (optional): fp32 [ceil(M/tile_m)][2][N] per-row-tile column sums / sums of
- * squares of (acc + bias), for train-mode BatchNorm; *stats_tiles receives the
- * number of row tiles written (may be NULL).
+ * stats (optional): fp32 [rows][2][N] partial column sums / sums of squares of (acc + bias) for train-mode
+ * BatchNorm, rows = sr_gemm_stats_tiles(M, N).  Every row is written in full (zeros where a workgroup had
+ * nothing left to add); their sum over rows is the batch sum, which is all sr_bn_finalize uses.  A row holds what one
+ * wave group of a workgroup accumulated over up to 32 of its row tiles.
  */
 typedef struct sr_gemm_args {
   sr_kpair kp[3];
@@ -74,10 +75,10 @@ typedef struct sr_gemm_args {
   float* stats;
 } sr_gemm_args;
 int sr_gemm(const sr_gemm_args* a, int dtype, void* stream);
-int sr_gemm_stats_tiles(int M, int N);
+int sr_gemm_stats_tiles(int M, int N);   /* rows of `stats` sr_gemm / sr_conv2d will write for (M, N) */
 /* Diagnostic only (synchronises!): copies the in-kernel cycle stamps of the last v3 GEMM launched with
  * SR_GEMM_DEBUG=4 to host memory: [256 blocks][8 waves][8] uint64 (0 vmcnt wait, 1 barrier, 2 DMA issue, 3 MFMA, 4 epilogue, 5 steps). */
-int sr_debug_stamps(unsigned long long* host_out, int count); /* rows of `stats` sr_gemm/sr_conv2d will write */
+int sr_debug_stamps(unsigned long long* host_out, int count);
 
 /* NHWC convolution as implicit GEMM on the same MFMA kernel:
  * y[b,ho,wo,co] = epilogue( sum_{r,q,c} x[b, ho*s-p+r, wo*s-p+q, c] * w[co,r,q,c] + bias[co] ) (+ res)

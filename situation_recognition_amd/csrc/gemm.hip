@@ -448,8 +448,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(c
 // WAVES_N = 1: 256x64 tile, 4 waves stacked along M (each 64x64 = 4x4 fragments), 3-slot ring (60 KiB), two workgroups per CU -- N <= 64
 // CFG = 8: 256x256 tile, FOUR waves (2x2, each 128x128 = 8x8 fragments), one wave per SIMD with the whole 512-register
 //          file, 64 MFMAs per wave between barriers, 16 fragment reads per 64 MFMAs, 4-slot ring.
-template <typename T, typename TO, bool CONV, int CFG, int EPI>
+//   EPIX = 1: linear WITH BatchNorm partial statistics (32 more live registers for the running sums); EPIX = 0: linear
+//   without them -- the registers go to a deeper residual prefetch instead.
+template <typename T, typename TO, bool CONV, int CFG, int EPIX>
 __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
+  constexpr int EPI = EPIX == 1 ? 0 : EPIX;
+  constexpr bool ST = EPIX == 1;
   constexpr int WAVES_N = CFG == 8 ? 2 : CFG, FN = CFG == 8 ? 8 : 4;   // FN: 16-column fragments per wave along N
   constexpr int WAVES_M = CFG == 1 ? 4 : 2, FM = 16 / WAVES_M;          // FM: 16-row fragments per wave along M
   constexpr int BM = 256, BN = 16 * FN * WAVES_N, NW = WAVES_M * WAVES_N;
@@ -601,7 +605,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
   // the column-tile count), so each lane keeps RUNNING per-column sums over its tiles and the 16-lane reduction + store
   // happens once per SR_STATS_FLUSH tiles, not once per tile (it was 4-5 K cycles of DPP chains per tile; the partial
   // buffer shrinks by the same factor: the stem's was 616 MB).  Row of flush f: ((vb / gn) * nflush + f) * WAVES_M + wm.
-  constexpr bool STATS_OK = EPI == 0;
+  constexpr bool STATS_OK = ST;
   constexpr int RSN = STATS_OK ? FN : 1;
   float rs1[RSN][4], rs2[RSN][4];
 #pragma unroll
@@ -757,12 +761,12 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     if (!p.no_store) {
     // 16-bit outputs with a residual: the residual is NOT fetched in fragment layout (4 scattered columns per lane) but as
     // whole 16-byte row chunks, coalesced, one strip ahead, and added (+ReLU) after the LDS transpose, on the output rows.
-    constexpr bool ROWRES = STAGED && EPI == 0;
+    constexpr bool ROWRES = STAGED && EPI == 0 && !ST;   // (statistics kernels: a residual takes the fragment-layout path; their registers hold the running sums)
     const bool rowres = ROWRES && p.res != nullptr;
     // The residual is requested RD strips ahead (RD*NH 16-byte loads per lane in flight, in the registers the K loop's
     // fragments no longer need): one strip ahead left every strip waiting a full HBM latency for its residual; all FM
     // strips at once spills.
-    constexpr int RD = FM < 3 ? FM : 3;
+    constexpr int RD = FM < 3 ? FM : 3;   // (6 strips ahead in the kernels without statistics registers: 6 % slower)
     uint4 rall[RD][NH];
     auto fetch_res = [&](int i, uint4 (&dst)[NH]) {
 #pragma unroll
@@ -1165,8 +1169,8 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
 constexpr int v3_threads(int CFG) { return (CFG == 1 || CFG == 8) ? 256 : 128 * CFG; }
 template <typename T, typename TO, int CFG, int EPI>
 __global__ __launch_bounds__(v3_threads(CFG), CFG == 8 ? 1 : 2) void gemm_nt_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, false, CFG, EPI>(p); }
-template <typename T, typename TO, int CFG>
-__global__ __launch_bounds__(v3_threads(CFG), CFG == 8 ? 1 : 2) void conv_igemm_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, true, CFG, 0>(p); }
+template <typename T, typename TO, int CFG, int EPIX>
+__global__ __launch_bounds__(v3_threads(CFG), CFG == 8 ? 1 : 2) void conv_igemm_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, true, CFG, EPIX>(p); }
 
 inline int num_cus() {
   static const int n = [] {
@@ -1262,19 +1266,27 @@ int launch_v3(const KArgs& k_in, hipStream_t st) {
   const unsigned grid = (unsigned)pl.grid;
   int rc = SR_OK;
   if (k.cv.on) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v3_kernel<T, TO, WN>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return SR_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN>), dim3(grid), dim3(NTHR), lds, st, k);
+    if (k.stats) {
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v3_kernel<T, TO, WN, 1>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (attr != hipSuccess) return SR_ERR_LAUNCH;
+      hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN, 1>), dim3(grid), dim3(NTHR), lds, st, k);
+    } else {
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v3_kernel<T, TO, WN, 0>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (attr != hipSuccess) return SR_ERR_LAUNCH;
+      hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN, 0>), dim3(grid), dim3(NTHR), lds, st, k);
+    }
   } else if constexpr (WN <= 2) {
-    rc = launch_v3e<T, TO, WN, 0>(k, grid, lds, st);          // narrow tiles: linear epilogue only (caller guarantees)
+    // narrow tiles: linear epilogue only (caller guarantees)
+    rc = k.stats ? launch_v3e<T, TO, WN, 1>(k, grid, lds, st) : launch_v3e<T, TO, WN, 0>(k, grid, lds, st);
   } else {
     switch (k.act) {
       case SR_ACT_SIGMOID: rc = launch_v3e<T, TO, WN, SR_ACT_SIGMOID>(k, grid, lds, st); break;
       case SR_ACT_TANH: rc = launch_v3e<T, TO, WN, SR_ACT_TANH>(k, grid, lds, st); break;
       case SR_ACT_SIGMOID_MUL: rc = launch_v3e<T, TO, WN, SR_ACT_SIGMOID_MUL>(k, grid, lds, st); break;
       case SR_ACT_TANH_BLEND: rc = launch_v3e<T, TO, WN, SR_ACT_TANH_BLEND>(k, grid, lds, st); break;
-      default: rc = launch_v3e<T, TO, WN, 0>(k, grid, lds, st); break;
+      default: rc = k.stats ? launch_v3e<T, TO, WN, 1>(k, grid, lds, st) : launch_v3e<T, TO, WN, 0>(k, grid, lds, st); break;
     }
   }
   if (rc != SR_OK) return rc;
