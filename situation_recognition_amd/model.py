@@ -14,6 +14,8 @@ depth (model.py:16 fixes ResNet-152), storage dtype (the reference uses fp16 aut
 import itertools
 from math import sqrt
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -539,6 +541,8 @@ class FCGGNN(nn.Module):
         self._shadow = _Shadow()
         self._drop_counter = 0
         self.drop_seed_base = 0x5eed
+        self.overlap_backbones = os.environ.get("SR_NO_OVERLAP") is None   # noun backbone on a second stream (see forward)
+        self._side_streams = {}
         self._noun_feat_cache = None
 
     def enable_graphs(self, on=True):
@@ -581,8 +585,24 @@ class FCGGNN(nn.Module):
 
     def forward(self, img, gt_verb):                                                    # model.py:172-180
         batch_size = img.size(0)
-        pred_verb = self.predict_verb(img, batch_size)
-        feat = self.convnet_nouns(img, bn_updates=2)
+        if self.overlap_backbones and img.is_cuda:
+            # The two backbones are independent: the noun backbone runs on a second HIP stream beside the verb path.  Every
+            # conv launch is a persistent grid of one workgroup per CU, so the other stream's workgroups move in as a
+            # kernel's last round of tiles drains, and its elementwise kernels fill the gaps between launches.
+            main = torch.cuda.current_stream()
+            side = self._side_streams.get(img.device)
+            if side is None:
+                side = self._side_streams[img.device] = torch.cuda.Stream(device=img.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                feat = self.convnet_nouns(img, bn_updates=2)
+            img.record_stream(side)
+            pred_verb = self.predict_verb(img, batch_size)
+            main.wait_stream(side)
+            feat.record_stream(main)
+        else:
+            pred_verb = self.predict_verb(img, batch_size)
+            feat = self.convnet_nouns(img, bn_updates=2)
         pred_nouns = self._nouns_from_features(feat, torch.argmax(pred_verb, 1), batch_size)
         gt_pred_nouns = self._nouns_from_features(feat, gt_verb, batch_size)
         return pred_verb, pred_nouns, gt_pred_nouns
