@@ -118,27 +118,46 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
-  // ---- pipeline: NS-1 stages in flight; issues past the slice's end read the zero page so the count stays fixed
+  // ---- pipeline: NS-1 stages in flight; issues past the slice's end read the zero page so the count stays fixed.
+  // The two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run half a stage apart, as in the GEMM kernel: an L
+  // section (all transposed fragment reads of the stage, the DMA of stage it+NS-1, wait for the reads) and an M section
+  // (the stage's MFMAs, no memory instruction), each closed by a barrier; group 1 starts one barrier late, so one wave of
+  // a SIMD reads LDS while the other multiplies (lock-step, the 36 reads and 34 MFMAs of a stage ran one after the other:
+  // 3500 cycles per stage for ~1100 of matrix-pipe time).  Barrier instances pair as G0.B1(it) = G1.B2(it-1),
+  // G0.B2(it) = G1.B1(it).  Stage it is read in L(it); every wave has waited for its own pieces of it before the last
+  // instance both groups pass ahead of that (G0: end of M(it-1); G1: in L(it-1)); the slot refilled in L(it) is the one
+  // stage it-1 was read from, drained (lgkmcnt 0) by both groups before their B1(it-1).
+  const int grp = wave >> 2;
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) issue(s);
+  gram_wait_vm<(NS - 2) * IPS>();        // my pieces of stage 0
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
   for (int it = 0; it < nst; ++it) {
-    gram_wait_vm<(NS - 2) * IPS>();      // my pieces of stage `it` have landed
-    __builtin_amdgcn_s_barrier();        // everybody's have, and everybody finished reading stage it-1
-    issue(it + NS - 1);                  // refill the slot stage it-1 used
     const char* imgA = smem + (it % NS) * SLOT;
     const char* imgB = TWO ? imgA + STAGE : imgA;
-    bf16x8_t a[2];
+    bf16x8_t a[2], b[FB];
     a[0] = frag(imgA, 2 * rg);
     a[1] = frag(imgA, 2 * rg + 1);
 #pragma unroll
+    for (int j = 0; j < FB; ++j) b[j] = frag(imgB, j);
+    issue(it + NS - 1);                  // refills the slot stage it-1 used
+    if (grp == 1) gram_wait_vm<(NS - 2) * IPS>();      // my pieces of stage it+1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();        // B1
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
     for (int j = 0; j < FB; ++j) {
-      const bf16x8_t b = frag(imgB, j);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b, acc[1][j], 0, 0, 0);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[j], acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[j], acc[1][j], 0, 0, 0);
     }
     cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ones, cs[0], 0, 0, 0);
     cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ones, cs[1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (grp == 0) gram_wait_vm<(NS - 2) * IPS>();      // my pieces of stage it+1
+    __builtin_amdgcn_s_barrier();        // B2
   }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
   gram_wait_vm<0>();                     // drain the padding DMAs before the workgroup's LDS goes away
 
   // ---- partial (slice, ks): lane holds D[a = 4g+r][b = lane&15]; stored transposed (G is used through the symmetric
