@@ -541,7 +541,10 @@ class FCGGNN(nn.Module):
         self._shadow = _Shadow()
         self._drop_counter = 0
         self.drop_seed_base = 0x5eed
-        self.overlap_backbones = os.environ.get("SR_NO_OVERLAP") is None   # noun backbone on a second stream (see forward)
+        # noun backbone on a second stream (see forward): True / False / None = automatic (per-GPU batches up to 2048, where it
+        # is worth 8 %; at 6144 it is worth 2 % and makes every kernel's duration in a profile depend on its neighbour's)
+        env = os.environ.get("SR_OVERLAP")
+        self.overlap_backbones = None if env is None else env not in ("0", "")
         self._side_streams = {}
         self._noun_feat_cache = None
 
@@ -585,7 +588,8 @@ class FCGGNN(nn.Module):
 
     def forward(self, img, gt_verb):                                                    # model.py:172-180
         batch_size = img.size(0)
-        if self.overlap_backbones and img.is_cuda:
+        overlap = self.overlap_backbones if self.overlap_backbones is not None else batch_size <= 2048
+        if overlap and img.is_cuda:
             # The two backbones are independent: the noun backbone runs on a second HIP stream beside the verb path.  Every
             # conv launch is a persistent grid of one workgroup per CU, so the other stream's workgroups move in as a
             # kernel's last round of tiles drains, and its elementwise kernels fill the gaps between launches.

@@ -106,8 +106,11 @@ def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_st
     if res is not None and (tuple(res.shape) != (B, Ho, Wo, Cout) or res.dtype != x.dtype):
         raise L.SrError("conv2d: residual shape/dtype mismatch")
     flops = 2.0 * B * Ho * Wo * Cout * KH * KH * Cin
+    es = x.element_size()
+    # algorithmic bytes: input and weights read once, output written once, residual read once
+    nbytes = es * (x.numel() + w.numel()) + (0 if stats_only else es * B * Ho * Wo * Cout) + (es * res.numel() if res is not None else 0)
     # a statistics-only launch re-does work the storing launch also does: its TIME counts, its FLOPs are not algorithmic
-    check(_timed("conv", 0.0 if stats_only else flops, 0, lambda: lib().sr_conv2d(C.byref(a), dtype_code(x.dtype), stream())), "sr_conv2d")
+    check(_timed("conv", 0.0 if stats_only else flops, float(nbytes), lambda: lib().sr_conv2d(C.byref(a), dtype_code(x.dtype), stream())), "sr_conv2d")
     if stats_only:
         return stats
     return (y, stats) if want_stats else y
