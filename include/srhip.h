@@ -179,6 +179,15 @@ int sr_gru_bwd2(const void* drh, const void* r, const void* h, void* dr_pre, voi
  * optional fp32 column sums colsum[C] += scale * sum_r in[r,c] (bias gradients). out may be NULL. */
 int sr_transpose(const void* in, int64_t ld_in, void* out, int64_t R, int64_t C, int64_t ld_out, int in_dtype,
                  int out_dtype, float* colsum, float colsum_scale, void* stream);
+/* out[N1, N2] (+)= A^T B for A [M, lda] (N1 columns) and B [M, ldb] (N2 columns), bf16, fp32 out with row stride N2;
+ * N1, N2 multiples of 256, any M.  The weight-gradient GEMM dW = dY^T X of the GGNN / classifier backward (autograd of the
+ * nn.Linear calls at reference model.py:64,75,80-83) without transposed copies of the operands: both MFMA operands are
+ * read out of row-major LDS images with transposed reads.  Rows are cut into sr_gemm_tn_slices(M, N1, N2) slices (so that
+ * small outputs still fill the chip), each writing an fp32 partial into scratch (>= slices*N1*N2 floats), folded into out
+ * (added to it when accumulate != 0). */
+int sr_gemm_tn_slices(int64_t M, int N1, int N2);
+int sr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int N1, int N2, int dtype, float* out,
+               int accumulate, float* scratch, int64_t scratch_floats, void* stream);
 /* colsum[C] += scale * sum_r in[r,c] */
 int sr_colsum(const void* in, int64_t ld_in, int64_t R, int64_t C, int dtype, float* colsum, float scale, void* stream);
 /* out[r, 0..Cpad) = cast(in[r, 0..C)), zero fill of [C, Cpad); row strides ld_in / ld_out */

@@ -64,6 +64,8 @@ SIGNATURES = {
     "sr_gru_bwd1": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "sr_gru_bwd2": [_P, _P, _P, _P, _P, _L, _I, _P],
     "sr_transpose": [_P, _L, _P, _L, _L, _L, _I, _I, _P, _F, _P],
+    "sr_gemm_tn_slices": [_L, _I, _I],
+    "sr_gemm_tn": [_P, _L, _P, _L, _L, _I, _I, _I, _P, _I, _P, _L, _P],
     "sr_colsum": [_P, _L, _L, _L, _I, _P, _F, _P],
     "sr_cast_pad": [_P, _L, _P, _L, _L, _L, _L, _I, _I, _P],
     "sr_cast": [_P, _P, _L, _I, _I, _P],

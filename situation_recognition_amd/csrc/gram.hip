@@ -25,6 +25,11 @@ typedef short s16x8_t __attribute__((ext_vector_type(8)));
 struct GramArgs {
   const bf16_t* x;     // [M, ldx]
   long M, ldx;
+  // TN GEMM mode (gram_kernel<256, true, true>): panel B comes from a second matrix, the block grid is nqa x nqb, the
+  // output block (a, b) is stored at rows b*256.., columns a*256.. of a [nqb*256][ldo] partial, no column sums
+  const bf16_t* xb;
+  long ldb, ldo;
+  int nqa, nqb;
   int C;
   float* partials;     // [nslices * KS][C*C + C]
   long pstride;        // C*C + C
@@ -45,8 +50,9 @@ template <int P> __device__ __forceinline__ int gram_swz(int row) {
 // P: panel width (channels a workgroup's Gram block spans per side).  TWO: C = 2P, the block's row and column
 // panels differ and are staged separately.  8 waves = RG row groups (32 channels of the A side each) x KS k-splits
 // (32-pixel sub-chunks of a stage); every stage is 16 KB per panel.
-template <int P, bool TWO>
+template <int P, bool TWO, bool TN = false>
 __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
+  static_assert(!TN || (TWO && P == 256), "TN GEMM mode: separate 256-column panels");
   constexpr int KS = 256 / P, RG = P / 32, FB = P / 16, SR = 32 * KS;
   constexpr int CPRW = P / 8, ROWB = P * 2, STAGE = SR * ROWB;
   constexpr int NPAN = TWO ? 2 : 1, NS = TWO ? 4 : 8, IPS = 2 * NPAN;
@@ -56,23 +62,24 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rg = wave % RG, ks = wave / RG;
-  const int npan = TWO ? 2 : 1;
-  const int quad = blockIdx.x % (npan * npan);
-  const long slice = blockIdx.x / (npan * npan);
-  const int colA0 = (quad / npan) * P, colB0 = (quad % npan) * P;
-  const bool diag = colA0 == colB0;
+  const int npa = TN ? p.nqa : (TWO ? 2 : 1), npb = TN ? p.nqb : npa;
+  const int quad = blockIdx.x % (npa * npb);
+  const long slice = blockIdx.x / (npa * npb);
+  const int colA0 = (quad / npb) * P, colB0 = (quad % npb) * P;
+  const bool diag = !TN && colA0 == colB0;
   const long r0 = slice * p.rows_per_wg;
   const long r1 = min(p.M, r0 + p.rows_per_wg);
   const int nst = (int)((r1 - r0 + SR - 1) / SR);
 
   // ---- loader: chunk q = j*512 + tid of a stage; LDS position q*16, data chunk (q % CPRW) ^ swz(row)
-  long src_off[2];
+  long src_off[2], src_offb[2];
   int src_row[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int q = j * 512 + tid, row = q / CPRW, slot = q % CPRW;
     src_row[j] = row;
     src_off[j] = (long)row * p.ldx + ((slot ^ gram_swz<P>(row)) * 8);
+    src_offb[j] = TN ? (long)row * p.ldb + ((slot ^ gram_swz<P>(row)) * 8) : src_off[j];
   }
   auto issue = [&](int st) {
     char* dst = smem + (st % NS) * SLOT + wave * 1024;
@@ -85,7 +92,8 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
                                        (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
       if (TWO) {
-        const bf16_t* sb = ok ? base + colB0 : (const bf16_t*)p.zero;
+        const bf16_t* baseb = TN ? p.xb + R * p.ldb + src_offb[j] : base;
+        const bf16_t* sb = ok ? baseb + colB0 : (const bf16_t*)p.zero;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
                                          (__attribute__((address_space(3))) void*)(dst + STAGE + j * 8192), 16, 0, 0);
       }
@@ -151,8 +159,10 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
       acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[j], acc[0][j], 0, 0, 0);
       acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[j], acc[1][j], 0, 0, 0);
     }
-    cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ones, cs[0], 0, 0, 0);
-    cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ones, cs[1], 0, 0, 0);
+    if (!TN) {
+      cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ones, cs[0], 0, 0, 0);
+      cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ones, cs[1], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
     if (grp == 0) gram_wait_vm<(NS - 2) * IPS>();      // my pieces of stage it+1
     __builtin_amdgcn_s_barrier();        // B2
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
 #pragma unroll
     for (int j = 0; j < FB; ++j) {
       const int cb = colB0 + 16 * j + t;
-      *reinterpret_cast<float4*>(out + (long)cb * p.C + ca) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      *reinterpret_cast<float4*>(out + (long)cb * (TN ? p.ldo : (long)p.C) + ca) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
     if (diag && t == 0)
       *reinterpret_cast<float4*>(out + (long)p.C * p.C + ca) = make_float4(cs[i][0], cs[i][1], cs[i][2], cs[i][3]);
@@ -301,7 +311,70 @@ int gram_launch(const GramArgs& a, const GramPlan& g, hipStream_t st) {
   return SR_OK;
 }
 
+// out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i]   (fp32; 4 elements per thread)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int nslices, long stride, long n4,
+                                                        float* __restrict__ out, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < nslices; ++k) {
+    const float4 v = reinterpret_cast<const float4*>(part + (long)k * stride)[i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = s;
+}
+
 }  // namespace
+
+/* out[N1, N2] (+)= A^T B for A [M, lda] (N1 columns), B [M, ldb] (N2 columns), bf16, fp32 out (row stride = N2): the
+ * weight-gradient GEMM dW = dY^T X without transposed copies of the operands.  Runs on the Gram kernel (both MFMA operands
+ * read through ds_read_b64_tr_b16); rows are cut into `nslices` slices so that (N1/256)*(N2/256)*nslices workgroups fill the
+ * chip, each slice writes an fp32 partial, tn_reduce_kernel folds them into out.  scratch: nslices*N1*N2 floats. */
+extern "C" int sr_gemm_tn_slices(int64_t M, int N1, int N2) {
+  if (M <= 0 || N1 <= 0 || N2 <= 0 || (N1 & 255) || (N2 & 255)) return SR_ERR_ARG;
+  const long blocks = (long)(N1 / 256) * (N2 / 256), ncu = gram_cus();
+  long n = (ncu + blocks - 1) / blocks;                 // one round of workgroups over the chip
+  const long max_by_rows = (M + 2047) / 2048;           // no slice shorter than 2048 rows
+  if (n > max_by_rows) n = max_by_rows;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+extern "C" int sr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int N1, int N2, int dtype, float* out,
+                          int accumulate, float* scratch, int64_t scratch_floats, void* stream) {
+  const int ns = sr_gemm_tn_slices(M, N1, N2);
+  if (ns < 0 || dtype != SR_BF16 || !A || !B || !out || !scratch || lda < N1 || ldb < N2 || (lda & 7) || (ldb & 7) ||
+      ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)out & 15) || ((uintptr_t)scratch & 15) ||
+      scratch_floats < (int64_t)ns * N1 * N2)
+    return SR_ERR_ARG;
+  static const void* zero = [] {
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_gram_zero)) != hipSuccess) z = nullptr;
+    return (const void*)z;
+  }();
+  if (!zero) return SR_ERR_LAUNCH;
+  constexpr int LDS = 131072;
+  static const bool once = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_kernel<256, true, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  if (!once) return SR_ERR_LAUNCH;
+  // the kernel stores block (a, b) transposed -- rows from panel B, four consecutive columns of panel A per lane -- so the
+  // matrix whose columns index out's COLUMNS goes in as panel A:  panel A = B (N2), panel B = A (N1)
+  GramArgs a{};
+  a.x = (const bf16_t*)B; a.ldx = ldb; a.xb = (const bf16_t*)A; a.ldb = lda; a.M = M;
+  a.nqa = N2 / 256; a.nqb = N1 / 256; a.ldo = N2; a.C = 0;
+  a.partials = scratch; a.pstride = (long)N1 * N2;
+  long rows = (M + ns - 1) / ns;
+  rows = (rows + 31) / 32 * 32;
+  a.rows_per_wg = rows; a.zero = zero;
+  const long nsl = (M + rows - 1) / rows;                // (<= ns)
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((gram_kernel<256, true, true>), dim3((unsigned)(nsl * a.nqa * a.nqb)), dim3(512), LDS, st, a);
+  const long n4 = (long)N1 * N2 / 4;
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)scratch, (int)nsl,
+                     (long)N1 * N2, n4, out, accumulate);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
 
 extern "C" int sr_gram_plan(int64_t M, int C, int64_t* npartials, int64_t* partial_floats) {
   GramPlan g;

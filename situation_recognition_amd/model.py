@@ -389,8 +389,14 @@ class _GGNNFunction(torch.autograd.Function):
         # Weight-gradient accumulators.  The four z/r matrices come out of ONE GEMM per step, [dz^T; dr^T] x [h^T; n^T]
         # (4096 x 4096 = 256 tiles: the whole chip, instead of four 64-tile launches), the two candidate matrices out of
         # dc^T x [n^T; (r*h)^T]; blocks are sliced apart at the end.
-        gZR = torch.zeros(2 * D, 2 * D, device=dev, dtype=torch.float32)      # rows: z | r ; cols: U (h) | W (n)
-        gC = torch.zeros(D, 2 * D, device=dev, dtype=torch.float32)           # cols: W_h (n) | U_h (r*h)
+        # bf16, D a multiple of 256: dW = dY^T X straight from the row-major operands (`sr_gemm_tn`: transposed LDS reads, rows
+        # cut into slices so that each 2048 x 2048 gradient fills the chip) -- no transposed copies, no stacking.
+        tn = dt == torch.bfloat16 and D % 256 == 0
+        if tn:
+            gW = {k: torch.zeros(D, D, device=dev, dtype=torch.float32) for k in ("Wz", "Uz", "Wr", "Ur", "Wh", "Uh")}
+        else:
+            gZR = torch.zeros(2 * D, 2 * D, device=dev, dtype=torch.float32)      # rows: z | r ; cols: U (h) | W (n)
+            gC = torch.zeros(D, 2 * D, device=dev, dtype=torch.float32)           # cols: W_h (n) | U_h (r*h)
         gP = torch.zeros(D, D, device=dev, dtype=torch.float32)
         gb = {k: torch.zeros(D, device=dev, dtype=torch.float32) for k in ("p", "z", "r", "h")}
         dh = dh.contiguous()
@@ -410,6 +416,14 @@ class _GGNNFunction(torch.autograd.Function):
             else:
                 dagg = ops.gemm([(dn, gT(Wp))])
                 dh = ops.aggregate(dagg, adj, idx, R, transpose=True, add=dacc)
+            if tn:
+                ops.colsum(dz, gb["z"]); ops.colsum(dr, gb["r"]); ops.colsum(dc, gb["h"])
+                ops.colsum(dn, gb["p"], scale=1.0 if verb else float(R))
+                ops.gemm_tn(dz, n, gW["Wz"]); ops.gemm_tn(dz, h, gW["Uz"])
+                ops.gemm_tn(dr, n, gW["Wr"]); ops.gemm_tn(dr, h, gW["Ur"])
+                ops.gemm_tn(dc, n, gW["Wh"]); ops.gemm_tn(dc, rh, gW["Uh"])
+                ops.gemm_tn(dn, h if verb else agg, gP)
+                continue
             # transposed operands (dW = dY^T X as NT GEMMs); bias gradients (column sums) are reduced inside the transpose kernel
             YT = torch.empty((2, D, Mp), device=dev, dtype=dt)         # dz^T, dr^T
             XT = torch.empty((3, D, Mp), device=dev, dtype=dt)         # h^T, n^T, (r*h)^T
@@ -424,6 +438,10 @@ class _GGNNFunction(torch.autograd.Function):
             ops.gemm([(YT.view(2 * D, Mp), XT[0:2].view(2 * D, Mp))], res=gZR, out=gZR, out_f32=True)
             ops.gemm([(dcT, XT[1:3].view(2 * D, Mp))], res=gC, out=gC, out_f32=True)
             ops.gemm([(dnT, aggT)], res=gP, out=gP, out_f32=True)
+        if tn:
+            grads = (gP, gb["p"], gW["Wz"], gb["z"], gW["Uz"], gb["z"].clone(), gW["Wr"], gb["r"], gW["Ur"], gb["r"].clone(),
+                     gW["Wh"], gb["h"], gW["Uh"], gb["h"].clone())
+            return (dh, None, None, None, None, None, None) + grads
         blk = lambda g_, i, j: g_[i * D:(i + 1) * D, j * D:(j + 1) * D].contiguous()
         grads = (gP, gb["p"], blk(gZR, 0, 1), gb["z"], blk(gZR, 0, 0), gb["z"].clone(), blk(gZR, 1, 1), gb["r"], blk(gZR, 1, 0),
                  gb["r"].clone(), blk(gC, 0, 0), gb["h"], blk(gC, 0, 1), gb["h"].clone())

@@ -168,6 +168,29 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
 
 
 _GRAM_SCRATCH = {}
+_TN_SCRATCH = {}
+
+
+def gemm_tn(A, B, out, accumulate=True):
+    """out[N1,N2] (+)= A^T @ B for A [M,N1], B [M,N2] (bf16, rows may be strided), out fp32 contiguous; N1, N2 multiples
+    of 256.  dW = dY^T X without transposed copies."""
+    require_gpu(out)
+    M, N1 = A.shape
+    N2 = B.shape[1]
+    if B.shape[0] != M or tuple(out.shape) != (N1, N2) or out.dtype != torch.float32 or A.stride(1) != 1 or B.stride(1) != 1:
+        raise L.SrError("gemm_tn: shape / layout mismatch")
+    ns = lib().sr_gemm_tn_slices(M, N1, N2)
+    if ns < 0:
+        raise L.SrError("gemm_tn: N1, N2 must be multiples of 256")
+    key = (out.device, torch.cuda.current_stream().cuda_stream)
+    scratch = _TN_SCRATCH.get(key)
+    if scratch is None or scratch.numel() < ns * N1 * N2:
+        scratch = _TN_SCRATCH[key] = torch.empty(ns * N1 * N2, device=out.device, dtype=torch.float32)
+    check(_timed("gemm", 2.0 * M * N1 * N2, 0, lambda: lib().sr_gemm_tn(
+        A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), M, N1, N2, dtype_code(A.dtype), out.data_ptr(), int(accumulate),
+        scratch.data_ptr(), scratch.numel(), stream())), "sr_gemm_tn")
+    return out
+
 
 
 def gram_plan(M, Cc):

@@ -335,3 +335,24 @@ def test_image_prep_u8_matches_totensor_normalize_crop_flip(ops, dtype):
     full = ops.image_prep_u8(img.cuda(), dtype)                         # no crop / flip
     want2 = ops.stem_prep(((img.float() / 255.0 - mean) / std).permute(0, 3, 1, 2).contiguous().cuda(), dtype)
     assert float((full.float() - want2.float()).abs().max()) <= (1e-6 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("M,N1,N2", [(1000, 256, 256), (4096 + 37, 512, 256), (36864, 256, 768)])
+def test_gemm_tn_weight_gradient(ops, M, N1, N2):
+    """sr_gemm_tn: out (+)= A^T B from row-major operands (ragged M: the last stage of a slice is padded from the zero
+    page; several row slices; accumulation into an existing gradient)."""
+    A = rnd(M, N1, dtype=torch.bfloat16, seed=1)
+    B = rnd(M, N2, dtype=torch.bfloat16, seed=2)
+    ref = A.double().t() @ B.double()
+    out = torch.zeros(N1, N2, device="cuda")
+    ops.gemm_tn(A.cuda(), B.cuda(), out, accumulate=False)
+    tol_ = 2e-6 * M ** 0.5 * float(A.double().abs().max() * B.double().abs().max()) + 1e-5 * float(ref.abs().max())
+    assert float((out.double().cpu() - ref).abs().max()) < tol_
+    ops.gemm_tn(A.cuda(), B.cuda(), out, accumulate=True)
+    assert float((out.double().cpu() - 2 * ref).abs().max()) < 2 * tol_
+    # strided operands (column slices of wider matrices)
+    wide = rnd(M, N1 + 256, dtype=torch.bfloat16, seed=3).cuda()
+    out2 = torch.empty(N1, N2, device="cuda")
+    ops.gemm_tn(wide[:, 256:], B.cuda(), out2, accumulate=False)
+    ref2 = wide[:, 256:].double().cpu().t() @ B.double()
+    assert float((out2.double().cpu() - ref2).abs().max()) < tol_
