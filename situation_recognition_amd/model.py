@@ -522,10 +522,16 @@ class _ClassifierFunction(torch.autograd.Function):
             dy = dy.contiguous()
         db = torch.zeros(N, device=dy.device, dtype=torch.float32)
         ops.colsum(dy, db)
-        dyp = ops.cast_pad(dy, dt, pad_to=64)                         # [M, Npad] storage dtype, zero padded
-        dx = ops.gemm([(dyp, shadow.get(W, dt, transposed=True, pad_to=64))])
+        tn = dt == torch.bfloat16 and W.shape[1] % 256 == 0
+        pad = 256 if tn else 64
+        dyp = ops.cast_pad(dy, dt, pad_to=pad)                        # [M, Npad] storage dtype, zero padded
+        dx = ops.gemm([(dyp, shadow.get(W, dt, transposed=True, pad_to=pad))])
         if drop_seed is not None:
             dx = ops.dropout_half(dx, drop_seed)
+        if tn:                                                        # dW = dy^T x from the row-major operands
+            dWp = torch.empty((dyp.shape[1], W.shape[1]), device=dy.device, dtype=torch.float32)
+            ops.gemm_tn(dyp, xd, dWp, accumulate=False)
+            return dx, dWp[:N], db, None, None
         dyT = ops.transpose(dyp, pad_to=kp)                           # [Npad, Mpad]
         xT = ops.transpose(xd, pad_to=kp)                             # [D, Mpad]
         dW = ops.gemm([(dyT[:N], xT)], out_f32=True)
