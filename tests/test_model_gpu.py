@@ -227,3 +227,34 @@ def test_uint8_nhwc_input_equals_normalised_fp32_input(sra):
         b = net(f32.cuda(), verb)
     for x, y in zip(a, b):
         assert float((x - y).abs().max()) < 1e-4
+
+
+def test_two_stream_backbones_give_identical_results(sra):
+    """FCGGNN.forward with the noun backbone on a second stream (the default for per-GPU batches up to 2048) against the
+    single-stream order: same kernels on the same data -> bit-identical outputs and running statistics, equal gradients."""
+    import copy
+    m, Enc = sra
+    enc = Enc.synthetic(V=12, NR=9, L=40, R=4)
+    torch.manual_seed(5)
+    a = m.FCGGNN(enc, 512, steps=3, backbone=50, width=16, dtype=torch.bfloat16).cuda().train()
+    b = copy.deepcopy(a)
+    a.overlap_backbones, b.overlap_backbones = True, False
+    a.drop_seed_base = b.drop_seed_base = 77
+    img = torch.randn(6, 3, 96, 96, device="cuda")
+    verb = torch.randint(0, 12, (6,), device="cuda")
+    nouns = torch.randint(0, 40, (6, 3, 4), device="cuda")
+    outs = []
+    for net in (a, b):
+        pv, pn, pg = net(img, verb)
+        loss = net.verb_loss(pv, verb) + net.nouns_loss(pn, nouns)
+        loss.backward()
+        torch.cuda.synchronize()
+        outs.append((pv, pn, pg))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        if p.requires_grad:      # (embedding gradients are float atomics: equal up to summation order)
+            assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-6 * float(q.grad.abs().max())), k
