@@ -838,9 +838,10 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         }
       }
       if (STAGED && !two) {
-        // the strip is wave-private: drain my LDS writes, then every lane moves 16 contiguous bytes (8 lanes = one
-        // 128-byte row segment) -> 2 store instructions per strip, full-line coalescing
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the strip is wave-private and a wave's LDS instructions execute in order: no wait between the fragment writes
+        // and the row reads (nor before the next strip's writes) -- only the compiler's own wait for the read data.
+        // Every lane moves 16 contiguous bytes (8 lanes = one 128-byte row segment) -> 2 store instructions per strip,
+        // full-line coalescing
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
           const int r16 = h * RPI + el / CPR, c8 = (el % CPR) * 8;
@@ -865,7 +866,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
           }
           const bool okk = (mm < p.M) && (nn + 8 <= Nv);
           if (okk || nn >= Nv || mm >= p.M) {
-            *reinterpret_cast<uint4*>(okk ? (char*)((TO*)p.C + mm * p.ldc + nn) : (char*)p.trash_page + el * 16) = val;
+            *reinterpret_cast<uint4*>(okk ? (char*)((TO*)p.C + mm * p.ldc + nn) : (char*)p.trash_page + el * 16) = val;   // (nontemporal: no difference)
           } else {  // ragged right edge (N not a multiple of 8): element-wise, still one "store slot"
             const unsigned wv[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
@@ -874,7 +875,6 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
                 reinterpret_cast<unsigned short*>(p.C)[mm * p.ldc + nn + e] = (unsigned short)(wv[e >> 1] >> ((e & 1) * 16));
           }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // strip reads done before the next strip overwrites it
       }
     }
     }
