@@ -693,7 +693,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
       for (int r = 0; r < 4; ++r) ev[j][r] = 1.f;
     if (scaled) {
       colvec(p.escale, ev);
-      if (want_stats) {
+      if (ST || want_stats) {       // (statistics kernels never keep the multipliers live: their registers hold the running sums)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -796,7 +796,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         const bool ok = (m < p.M) && (n < Nv);
         float v[4], o2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(acc[j][i][r], ev[j][r], bv[j][r]);
+        for (int r = 0; r < 4; ++r) v[r] = ST ? acc[j][i][r] + bv[j][r] : __builtin_fmaf(acc[j][i][r], ev[j][r], bv[j][r]);
         if (p.res && !rowres) {
           float rv[4];
           load4<TO>(ok ? (const TO*)p.res + m * p.ldres + n : zeros, rv);
