@@ -864,16 +864,11 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
               val = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             }
           }
+          // (16-bit outputs whose N is not a multiple of 8 never reach this kernel -- `launch` sends them to the v2 kernels --
+          //  so a 16-byte chunk is either wholly inside the matrix or wholly outside: an element-wise ragged-edge path here
+          //  put ~70 predicated instructions into every strip of every tile)
           const bool okk = (mm < p.M) && (nn + 8 <= Nv);
-          if (okk || nn >= Nv || mm >= p.M) {
-            *reinterpret_cast<uint4*>(okk ? (char*)((TO*)p.C + mm * p.ldc + nn) : (char*)p.trash_page + el * 16) = val;   // (nontemporal: no difference)
-          } else {  // ragged right edge (N not a multiple of 8): element-wise, still one "store slot"
-            const unsigned wv[4] = {val.x, val.y, val.z, val.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (nn + e < Nv)
-                reinterpret_cast<unsigned short*>(p.C)[mm * p.ldc + nn + e] = (unsigned short)(wv[e >> 1] >> ((e & 1) * 16));
-          }
+          *reinterpret_cast<uint4*>(okk ? (char*)((TO*)p.C + mm * p.ldc + nn) : (char*)p.trash_page + el * 16) = val;   // (nontemporal: no difference)
         }
       }
     }
@@ -1325,7 +1320,10 @@ inline int v3_cfg(long M, int N, bool linear) {
 template <typename T, typename TO>
 int launch(const KArgs& k, hipStream_t st) {
   const bool linear = k.act == SR_ACT_NONE || k.act == SR_ACT_RELU;
-  switch (v3_cfg(k.M, k.N, linear)) {
+  // N not a multiple of 8: 16-bit outputs (see the staged store of the v3 epilogue) and launches with statistics
+  // (sr_gemm_stats_tiles does not know the output type) take the v2 kernels
+  const bool ragged16 = (k.N & 7) != 0 && (sizeof(TO) == 2 || k.stats != nullptr);
+  switch (ragged16 ? 0 : v3_cfg(k.M, k.N, linear)) {
     case 4: return launch_v3<T, TO, 4>(k, st);
     case 2: return launch_v3<T, TO, 2>(k, st);
     case 1: return launch_v3<T, TO, 1>(k, st);
@@ -1374,7 +1372,7 @@ extern "C" int sr_debug_stamps(unsigned long long* host_out, int count) {
 
 extern "C" int sr_gemm_stats_tiles(int M, int N) {
   const int gm = (M + 255) / 256;
-  const int cfg = v3_cfg(M, N, true);    // statistics are only produced with a linear epilogue
+  const int cfg = (N & 7) ? 0 : v3_cfg(M, N, true);    // statistics are only produced with a linear epilogue
   if (cfg == 0) return gm;               // v2: one row per 256-row tile
   // v3: one row per (workgroup column-tile group, flush, wave group): each workgroup keeps running sums over up to
   // SR_STATS_FLUSH of its tiles (all of which cover the same columns)
