@@ -84,6 +84,13 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
   *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(t);
 }
 
+// max(x, 0) as ONE instruction: fmaxf() makes hipcc canonicalise its operand first (a second v_max_f32 per element)
+__device__ __forceinline__ float relu1(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 // =====================================================================================================
 // v2: persistent workgroups + 3-stage LDS-DMA ring (default).
 //
@@ -806,7 +813,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         if constexpr (EPI == 0) {
           if (relu && !rowres) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            for (int r = 0; r < 4; ++r) v[r] = relu1(v[r]);
           }
         } else if constexpr (EPI == SR_ACT_SIGMOID) {
 #pragma unroll
@@ -857,7 +864,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
               for (int q = 0; q < 4; ++q) {
                 float lo = __uint_as_float(pv_[q] << 16) + __uint_as_float(pr_[q] << 16);
                 float hi = __uint_as_float(pv_[q] & 0xffff0000u) + __uint_as_float(pr_[q] & 0xffff0000u);
-                if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                if (relu) { lo = relu1(lo); hi = relu1(hi); }
                 bf16_t pk[2] = {(bf16_t)lo, (bf16_t)hi};
                 ow[q] = *reinterpret_cast<const unsigned*>(pk);
               }
