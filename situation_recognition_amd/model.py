@@ -565,8 +565,9 @@ class FCGGNN(nn.Module):
         self._shadow = _Shadow()
         self._drop_counter = 0
         self.drop_seed_base = 0x5eed
-        # noun backbone on a second stream (see forward): True / False / None = automatic (per-GPU batches up to 2048, where it
-        # is worth 8 %; at 6144 it is worth 2 % and makes every kernel's duration in a profile depend on its neighbour's)
+        # noun backbone on a second stream (see forward): True / False / None = automatic (per-GPU batches up to 4096: worth 8 %
+        # at 768, 4 % at 1536 and 3072; at 6144 it is worth 2 % and makes every kernel's duration in a profile depend on its
+        # neighbour's)
         env = os.environ.get("SR_OVERLAP")
         self.overlap_backbones = None if env is None else env not in ("0", "")
         self._side_streams = {}
@@ -612,7 +613,7 @@ class FCGGNN(nn.Module):
 
     def forward(self, img, gt_verb):                                                    # model.py:172-180
         batch_size = img.size(0)
-        overlap = self.overlap_backbones if self.overlap_backbones is not None else batch_size <= 2048
+        overlap = self.overlap_backbones if self.overlap_backbones is not None else batch_size <= 4096
         if overlap and img.is_cuda:
             # The two backbones are independent: the noun backbone runs on a second HIP stream beside the verb path.  Every
             # conv launch is a persistent grid of one workgroup per CU, so the other stream's workgroups move in as a

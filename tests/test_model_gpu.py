@@ -230,7 +230,7 @@ def test_uint8_nhwc_input_equals_normalised_fp32_input(sra):
 
 
 def test_two_stream_backbones_give_identical_results(sra):
-    """FCGGNN.forward with the noun backbone on a second stream (the default for per-GPU batches up to 2048) against the
+    """FCGGNN.forward with the noun backbone on a second stream (the default for per-GPU batches up to 4096) against the
     single-stream order: same kernels on the same data -> bit-identical outputs and running statistics, equal gradients."""
     import copy
     m, Enc = sra
