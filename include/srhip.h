@@ -134,6 +134,10 @@ int sr_bn_finalize(const float* stats, int tiles, int C, int64_t count, const fl
  *                       scratch: fp64 workspace of at least 66*(C*C + C) elements. */
 int sr_gram_plan(int64_t M, int C, int64_t* npartials, int64_t* partial_floats);
 int sr_gram(const void* x, int64_t M, int C, int64_t ldx, int dtype, float* partials, int64_t npartials, void* stream);
+/* sr_bn_apply (ReLU, no residual, in place) + sr_gram in one pass: x holds the raw output of the bottleneck's 3x3 conv on
+ * entry and its normalised form on return; partials as sr_gram (C in {64,128,256}). */
+int sr_bn_apply_gram(void* x, int64_t M, int C, int64_t ldx, int dtype, const float* scale, const float* shift,
+                     float* partials, int64_t npartials, void* stream);
 int sr_bn_finalize_gram(const float* partials, int64_t npartials, int C, const void* w, int64_t ldw, int N, int dtype,
                         int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
                         float momentum, float eps, float* scale, float* shift, double* scratch, int64_t scratch_elems,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "sr_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P],
     "sr_gram_plan": [_L, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "sr_gram": [_P, _L, _I, _L, _I, _P, _L, _P],
+    "sr_bn_apply_gram": [_P, _L, _I, _L, _I, _P, _P, _P, _L, _P],
     "sr_bn_finalize_gram": [_P, _L, _I, _P, _L, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _P],
     "sr_bn_apply": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "sr_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P],

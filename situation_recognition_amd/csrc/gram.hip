@@ -18,6 +18,7 @@
 namespace {
 
 __device__ __attribute__((aligned(256))) unsigned char g_gram_zero[256];
+__device__ __attribute__((aligned(256))) unsigned char g_gram_trash[512 * 16];   // sink for the stores of rows past the slice (fixed store count per stage: vmcnt)
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
@@ -30,6 +31,10 @@ struct GramArgs {
   const bf16_t* xb;
   long ldb, ldo;
   int nqa, nqb;
+  // FUSE mode: x holds RAW conv output; every stage is normalised in place (x = relu(x*scale[c] + shift[c]), in LDS and
+  // in global memory) before it enters the Gram sums -- bn_apply and gram in one pass over the tensor
+  const float* scale; const float* shift;
+  void* trash;
   int C;
   float* partials;     // [nslices * KS][C*C + C]
   long pstride;        // C*C + C
@@ -50,9 +55,10 @@ template <int P> __device__ __forceinline__ int gram_swz(int row) {
 // P: panel width (channels a workgroup's Gram block spans per side).  TWO: C = 2P, the block's row and column
 // panels differ and are staged separately.  8 waves = RG row groups (32 channels of the A side each) x KS k-splits
 // (32-pixel sub-chunks of a stage); every stage is 16 KB per panel.
-template <int P, bool TWO, bool TN = false>
+template <int P, bool TWO, bool TN = false, bool FUSE = false>
 __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
   static_assert(!TN || (TWO && P == 256), "TN GEMM mode: separate 256-column panels");
+  static_assert(!FUSE || (!TWO && !TN), "fused BatchNorm apply: single panel only");
   constexpr int KS = 256 / P, RG = P / 32, FB = P / 16, SR = 32 * KS;
   constexpr int CPRW = P / 8, ROWB = P * 2, STAGE = SR * ROWB;
   constexpr int NPAN = TWO ? 2 : 1, NS = TWO ? 4 : 8, IPS = 2 * NPAN;
@@ -100,6 +106,46 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
     }
   };
 
+  // ---- FUSE: a lane normalises the two 16-byte chunks IT loaded of a stage (they hold the same 8 channels: the chunk
+  // index of q = j*512 + tid does not depend on j), in LDS and in global memory.  Rows past the slice stay zero.
+  // (scale / shift live in LDS behind the ring, 2 x P floats: 16 more loop-carried registers made the 256-wide kernel spill)
+  float* const lds_sc = reinterpret_cast<float*>(smem + NS * SLOT);
+  const int c8 = ((tid % CPRW) ^ gram_swz<P>(tid / CPRW)) * 8;
+  if (FUSE) {
+    if (tid < P) { lds_sc[tid] = p.scale[tid]; lds_sc[P + tid] = p.shift[tid]; }
+    __syncthreads();
+  }
+  auto normalise = [&](int st) {
+    char* img = smem + (st % NS) * SLOT + wave * 1024 + lane * 16;
+    const long R = r0 + (long)st * SR;
+    float nsc[8], nsh[8];
+    {
+      const float4 s0 = *reinterpret_cast<const float4*>(lds_sc + c8), s1 = *reinterpret_cast<const float4*>(lds_sc + c8 + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(lds_sc + P + c8), h1 = *reinterpret_cast<const float4*>(lds_sc + P + c8 + 4);
+      nsc[0] = s0.x; nsc[1] = s0.y; nsc[2] = s0.z; nsc[3] = s0.w; nsc[4] = s1.x; nsc[5] = s1.y; nsc[6] = s1.z; nsc[7] = s1.w;
+      nsh[0] = h0.x; nsh[1] = h0.y; nsh[2] = h0.z; nsh[3] = h0.w; nsh[4] = h1.x; nsh[5] = h1.y; nsh[6] = h1.z; nsh[7] = h1.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = st < nst && R + src_row[j] < r1;
+      uint4 v = *reinterpret_cast<const uint4*>(img + j * 8192);
+      unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float lo = __builtin_fmaf(__uint_as_float(w[q] << 16), nsc[2 * q], nsh[2 * q]);
+        float hi = __builtin_fmaf(__uint_as_float(w[q] & 0xffff0000u), nsc[2 * q + 1], nsh[2 * q + 1]);
+        lo = lo > 0.f ? lo : 0.f;
+        hi = hi > 0.f ? hi : 0.f;
+        bf16_t pk[2] = {(bf16_t)lo, (bf16_t)hi};
+        w[q] = ok ? *reinterpret_cast<const unsigned*>(pk) : 0u;         // rows past the slice stay zero
+      }
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<uint4*>(img + j * 8192) = v;
+      // exactly one store per piece (rows past the slice: the trash page), so that the vmcnt arithmetic below holds
+      *reinterpret_cast<uint4*>(ok ? (char*)(const_cast<bf16_t*>(p.x) + R * p.ldx + src_off[j]) : (char*)p.trash + tid * 16) = v;
+    }
+  };
+
   // ---- transposed-read addressing: lane (g = lane>>4, q = (lane>>2)&3, pp = lane&3) supplies row 8g+q (+4 for the
   // second read), 8-byte piece pp of the block's 32-byte row segment
   const int g = lane >> 4, tq = (lane >> 2) & 3, pp = lane & 3;
@@ -139,6 +185,13 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) issue(s);
   gram_wait_vm<(NS - 2) * IPS>();        // my pieces of stage 0
+  if (FUSE) {
+    // a stage is normalised by its loaders right after their own wait for it, at the end of an M section (the fragment
+    // registers are dead there): group 0 does stage it+1 there, group 1 -- whose wait sits a barrier earlier -- stage it+2
+    normalise(0);                                       // (+2 stores, younger than every DMA so far)
+    if (grp == 1) { gram_wait_vm<(NS - 3) * IPS + 2>(); normalise(1); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();
   for (int it = 0; it < nst; ++it) {
@@ -150,7 +203,7 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
 #pragma unroll
     for (int j = 0; j < FB; ++j) b[j] = frag(imgB, j);
     issue(it + NS - 1);                  // refills the slot stage it-1 used
-    if (grp == 1) gram_wait_vm<(NS - 2) * IPS>();      // my pieces of stage it+1
+    if (!FUSE && grp == 1) gram_wait_vm<(NS - 2) * IPS>();      // my pieces of stage it+1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();        // B1
     __builtin_amdgcn_s_setprio(1);
@@ -164,7 +217,22 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
       cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ones, cs[1], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
-    if (grp == 0) gram_wait_vm<(NS - 2) * IPS>();      // my pieces of stage it+1
+    if (FUSE) {
+      // vmcnt counts the 2 stores of every normalise() too, in issue order with the DMAs (one DMA pair per L section, one
+      // store pair per M section): younger than the pieces of stage it+1 are 6 DMA stages + 6 store pairs (group 0),
+      // than those of stage it+2 5 + 5 (group 1).  In the first iterations fewer store pairs have been issued yet, so
+      // FEWER operations are younger: there the count without any stores is used (stricter, always safe).
+      if (grp == 0) {
+        if (it >= NS - 3) gram_wait_vm<(NS - 2) * (IPS + 2)>(); else gram_wait_vm<(NS - 2) * IPS>();
+        normalise(it + 1);
+      } else {
+        if (it >= NS - 5) gram_wait_vm<(NS - 3) * (IPS + 2)>(); else gram_wait_vm<(NS - 3) * IPS>();
+        normalise(it + 2);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my LDS writes are in place before the barrier
+    } else if (grp == 0) {
+      gram_wait_vm<(NS - 2) * IPS>();    // my pieces of stage it+1
+    }
     __builtin_amdgcn_s_barrier();        // B2
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
@@ -299,15 +367,15 @@ bool gram_plan(int64_t M, int C, GramPlan* g) {
   return true;
 }
 
-template <int P, bool TWO>
+template <int P, bool TWO, bool FUSE = false>
 int gram_launch(const GramArgs& a, const GramPlan& g, hipStream_t st) {
-  constexpr int LDS = 131072;
+  constexpr int LDS = 131072 + (FUSE ? 2 * P * 4 : 0);
   static bool once = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_kernel<P, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) ==
-           hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_kernel<P, TWO, false, FUSE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   }();
   if (!once) return SR_ERR_LAUNCH;
-  hipLaunchKernelGGL((gram_kernel<P, TWO>), dim3((unsigned)(g.nslices * g.npan * g.npan)), dim3(512), LDS, st, a);
+  hipLaunchKernelGGL((gram_kernel<P, TWO, false, FUSE>), dim3((unsigned)(g.nslices * g.npan * g.npan)), dim3(512), LDS, st, a);
   return SR_OK;
 }
 
@@ -405,6 +473,41 @@ extern "C" int sr_gram(const void* x, int64_t M, int C, int64_t ldx, int dtype, 
     case 128: rc = gram_launch<128, false>(a, g, st); break;
     case 256: rc = gram_launch<256, false>(a, g, st); break;
     default: rc = gram_launch<256, true>(a, g, st); break;
+  }
+  if (rc != SR_OK) return rc;
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+/* x = relu(x*scale[c] + shift[c]) in place (what sr_bn_apply does after the 3x3 conv of a bottleneck) AND the Gram partials of
+ * the result for the expansion conv that follows, in one pass over the tensor (C in {64,128,256}; layout of `partials` as
+ * sr_gram). */
+extern "C" int sr_bn_apply_gram(void* x, int64_t M, int C, int64_t ldx, int dtype, const float* scale, const float* shift,
+                                float* partials, int64_t npartials, void* stream) {
+  GramPlan g;
+  if (dtype != SR_BF16 || !x || !partials || !scale || !shift || !gram_plan(M, C, &g) || g.npan != 1 || npartials != g.npartials ||
+      ldx < C || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)partials & 15))
+    return SR_ERR_ARG;
+  static const void* zero = [] {
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_gram_zero)) != hipSuccess) z = nullptr;
+    return (const void*)z;
+  }();
+  static void* trash = [] {
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_gram_trash)) != hipSuccess) z = nullptr;
+    return z;
+  }();
+  if (!zero || !trash) return SR_ERR_LAUNCH;
+  GramArgs a{};
+  a.x = (const bf16_t*)x; a.M = M; a.ldx = ldx; a.C = C; a.partials = partials; a.pstride = (long)C * C + C;
+  a.rows_per_wg = g.rows_per_wg; a.zero = zero; a.scale = scale; a.shift = shift; a.trash = trash;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  switch (C) {
+    case 64: rc = gram_launch<64, false, true>(a, g, st); break;
+    case 128: rc = gram_launch<128, false, true>(a, g, st); break;
+    default: rc = gram_launch<256, false, true>(a, g, st); break;
   }
   if (rc != SR_OK) return rc;
   SR_CHECK_LAUNCH();

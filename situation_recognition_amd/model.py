@@ -195,6 +195,7 @@ class resnet(nn.Module):
         self._graphs = {}
         self._stats_epoch = 0          # bumped whenever a train-mode pass changed running statistics
         self._pending_tracked = 0      # num_batches_tracked increments not yet written to the buffers
+        self._gram_stash = None        # (data_ptr, Gram partials) a fused BN-apply left for the expansion conv that follows
         self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_counters())
 
     # -- bookkeeping
@@ -222,7 +223,14 @@ class resnet(nn.Module):
         return self._units
 
     # -- execution
-    def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False):
+    def _gram_route(self, u, n_pixels):
+        """Does expansion conv `u` take its batch statistics from the Gram matrix of its input?"""
+        return (self.two_pass and self.gram_stats and self.dtype == torch.bfloat16 and u.k == 1 and u.stride == 1 and u.cout_p > 128
+                and u.cin_p in (64, 128, 256, 512) and u.cout_p >= 4 * u.cin_p
+                and n_pixels >= 256 * u.cin_p)    # (below ~256*C pixels the fixed cost of the fp64 finalize loses to launch 1)
+
+    def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False, then=None):
+        """`then`: the unit that consumes this one's output next (lets BN-apply and the consumer's Gram pass share one sweep)."""
         dt = self.dtype
         if not train:
             w, b = u.folded(dt, self._stats_epoch)
@@ -236,11 +244,11 @@ class resnet(nn.Module):
             # cheap GEMM and applies scale/shift (+identity, ReLU) in its epilogue.  HBM traffic per output element drops
             # from 5 accesses (write raw, read raw, read identity, write) to 2 (read identity, write).
             Ho, Wo = (x.shape[1] - 1) // u.stride + 1, (x.shape[2] - 1) // u.stride + 1
-            if (self.gram_stats and dt == torch.bfloat16 and u.stride == 1 and u.cin_p in (64, 128, 256, 512) and u.cout_p >= 4 * u.cin_p
-                    and x.shape[0] * Ho * Wo >= 256 * u.cin_p):   # (below ~256*C pixels the fixed cost of the fp64 finalize loses to launch 1)
+            if self._gram_route(u, x.shape[0] * Ho * Wo):
                 # Expansion conv (N = 4C): its batch statistics follow from the C x C Gram matrix of the input
                 # (sum y^2 = w G w^T), a quarter of the conv's MFMA work and one read of x -- no launch 1 at all.
-                part = ops.gram(x.view(-1, u.cin_p))
+                stash, self._gram_stash = self._gram_stash, None
+                part = stash[1] if stash is not None and stash[0] == x.data_ptr() else ops.gram(x.view(-1, u.cin_p))
                 scale, shift = ops.bn_finalize_gram(part, w.view(u.cout_p, u.cin_p), x.shape[0] * Ho * Wo, gamma, beta, rm, rv,
                                                     momentum, u.bn.eps)
             else:
@@ -255,6 +263,12 @@ class resnet(nn.Module):
             u.writeback(rm, rv)
         if pool_after:                                  # BN + ReLU applied inside the pooling window
             return ops.maxpool3x3s2(y, scale, shift)
+        if (then is not None and relu and res is None and u.cout_p <= 256 and then.cin_p == u.cout_p
+                and self._gram_route(then, y.numel() // u.cout_p)):
+            # the consumer is an expansion conv on the Gram route: normalise in place AND accumulate its Gram partials in one
+            # sweep over y (`sr_bn_apply_gram`) instead of bn_apply now and a second read of the same tensor by sr_gram
+            self._gram_stash = (y.data_ptr(), ops.bn_apply_gram(y.view(-1, u.cout_p), scale, shift))
+            return y
         return ops.bn_apply(y, scale, shift, res=res, relu=relu, out=y)
 
     def forward(self, x, bn_updates=1):
@@ -307,8 +321,8 @@ class resnet(nn.Module):
             for convs, ds in blocks:
                 idn = a if ds is None else self._unit(a, ds, train, momentum, relu=False)
                 y = a
-                for u in convs[:-1]:
-                    y = self._unit(y, u, train, momentum, relu=True)
+                for i, u in enumerate(convs[:-1]):
+                    y = self._unit(y, u, train, momentum, relu=True, then=convs[i + 1] if i + 2 == len(convs) else None)
                 a = self._unit(y, convs[-1], train, momentum, relu=True, res=idn)
             feat = ops.avgpool(a)
         if train:

@@ -212,6 +212,18 @@ def gram(x2d):
     return part
 
 
+def bn_apply_gram(x2d, scale, shift):
+    """x2d [M, C] <- relu(x2d*scale + shift) in place, and the Gram partials of the result (one pass)."""
+    require_gpu(x2d, scale, shift)
+    M, Cc = x2d.shape
+    n, f = gram_plan(M, Cc)
+    part = torch.empty((n, f), device=x2d.device, dtype=torch.float32)
+    check(_timed("gram", 0.0, 4.0 * M * Cc, lambda: lib().sr_bn_apply_gram(x2d.data_ptr(), M, Cc, x2d.stride(0), dtype_code(x2d.dtype),
+                                                                          scale.data_ptr(), shift.data_ptr(), part.data_ptr(), n,
+                                                                          stream())), "sr_bn_apply_gram")
+    return part
+
+
 def bn_finalize_gram(part, w, count, gamma, beta, running_mean, running_var, momentum, eps):
     """Train-mode BN scale/shift (+ EMA) of the 1x1 conv with packed weights w [N, C] whose input has the partial Grams `part`."""
     require_gpu(part, w, gamma, beta, running_mean, running_var)

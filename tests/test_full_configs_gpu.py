@@ -103,11 +103,16 @@ def test_gram_statistics_route_matches_statistics_only_launch_in_the_backbone():
     net = resnet(None, depth=50, dtype=torch.bfloat16).cuda().train()
     img = torch.randn(352, 3, 224, 224, device="cuda").clamp_(-2.2, 2.7)
     seen, last_x = [], {}
-    gram0, fin0 = ops.gram, ops.bn_finalize_gram
+    gram0, fin0, fused0 = ops.gram, ops.bn_finalize_gram, ops.bn_apply_gram
 
     def gram(x2d):
         last_x["x"] = x2d
         return gram0(x2d)
+
+    def fused(x2d, scale, shift):                # BN-apply of the 3x3's output + Gram partials in one sweep (in place)
+        part = fused0(x2d, scale, shift)
+        last_x["x"] = x2d
+        return part
 
     def fin(part, w, count, gamma, beta, rm, rv, momentum, eps):
         scale, shift = fin0(part, w, count, gamma, beta, rm, rv, momentum, eps)
@@ -117,11 +122,11 @@ def test_gram_statistics_route_matches_statistics_only_launch_in_the_backbone():
         seen.append((w.shape[1], float(((scale - s2).abs() / s2.abs().clamp_min(1e-3)).max()), float((shift - h2).abs().max())))
         return scale, shift
 
-    ops.gram, ops.bn_finalize_gram = gram, fin
+    ops.gram, ops.bn_finalize_gram, ops.bn_apply_gram = gram, fin, fused
     try:
         f = net(img)
     finally:
-        ops.gram, ops.bn_finalize_gram = gram0, fin0
+        ops.gram, ops.bn_finalize_gram, ops.bn_apply_gram = gram0, fin0, fused0
     assert torch.isfinite(f).all()
     assert sorted(set(c for c, _, _ in seen)) == [64, 128, 256] and len(seen) == (3 + 1) + 4 + 6   # (+1: layer1's stride-1 downsample)
     for c, ds, dh in seen:

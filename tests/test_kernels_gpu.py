@@ -356,3 +356,26 @@ def test_gemm_tn_weight_gradient(ops, M, N1, N2):
     ops.gemm_tn(wide[:, 256:], B.cuda(), out2, accumulate=False)
     ref2 = wide[:, 256:].double().cpu().t() @ B.double()
     assert float((out2.double().cpu() - ref2).abs().max()) < tol_
+
+
+@pytest.mark.parametrize("M,C", [(980, 64), (70001, 64), (33333, 128), (980, 256), (50000, 256)])
+def test_bn_apply_gram_fused(ops, M, C):
+    """sr_bn_apply_gram = sr_bn_apply (ReLU, in place) followed by sr_gram, in one pass: the normalised tensor equals
+    bn_apply's (both are one fp32 FMA + ReLU + round to bf16 per element) and the partials equal gram's on that tensor."""
+    x = rnd(M, C, dtype=torch.bfloat16, seed=M + C)
+    sc, sh = 0.5 + torch.rand(C), rnd(C, seed=3, scale=0.5)
+    xa = x.cuda().clone()
+    ops.bn_apply(xa, sc.cuda(), sh.cuda(), relu=True, out=xa)
+    pa = ops.gram(xa)
+    xb = x.cuda().clone()
+    pb = ops.bn_apply_gram(xb, sc.cuda(), sh.cuda())
+    ref = torch.relu(x.float() * sc + sh)
+    assert float((xb.float().cpu() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
+    assert float((xb.float() - xa.float()).abs().max()) <= 8e-3 * float(ref.abs().max())       # (at most one bf16 ulp apart)
+    assert pb.shape == pa.shape
+    ta, tb = pa.double().sum(0), pb.double().sum(0)
+    xd = xb.double()
+    G = (xd.t() @ xd).cpu()
+    assert float((tb[: C * C].view(C, C).cpu() - G).abs().max()) < 1e-5 * float(G.diagonal().max())
+    assert float((tb[C * C:].cpu() - xd.sum(0).cpu()).abs().max()) < 1e-5 * float(xd.abs().sum(0).max())
+    assert float((ta - tb).abs().max()) <= 2e-2 * float(ta.abs().max())

@@ -30,6 +30,11 @@ for name, hw, C in (("layer1", 56, 64), ("layer2", 28, 128), ("layer3", 14, 256)
     st = ops.conv2d(x, w, N, 1, 1, 0, stats_only=True)
     t_c = timed(lambda: ops.conv2d(x, w, N, 1, 1, 0, stats_only=True))
     t_b = timed(lambda: ops.bn_finalize(st, M, gamma, beta, None, None, 0.1, 1e-5))
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    x2 = x.view(-1, C).clone()
+    t_ap = timed(lambda: ops.bn_apply(x2, sc, sh, relu=True, out=x2))
+    t_fu = timed(lambda: ops.bn_apply_gram(x2, sc, sh)) if C <= 256 else float("nan")
+    print("   fused bn_apply+gram %7.1f us (%5.2f TB/s r+w)  vs  bn_apply %7.1f us + gram %7.1f us" % (t_fu, 4.0 * M * C / t_fu / 1e6, t_ap, t_g))
     s1, h1 = ops.bn_finalize_gram(part, w, M, gamma, beta, None, None, 0.1, 1e-5)
     s2, h2 = ops.bn_finalize(st, M, gamma, beta, None, None, 0.1, 1e-5)
     print("%s M=%9d C=%3d | gram %7.1f us (%5.2f TB/s of x) + finalize %6.1f us | stats-only conv %7.1f us + finalize %6.1f us | "
