@@ -100,8 +100,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
   }
 }
 
-// Stage B: 64 channels x 16 chunk-groups per workgroup; fixed summation order (deterministic).
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ scratch, int chunks, int C, double inv_count,
+// Stage B: 64 channels x 16 chunk-groups per workgroup; fixed summation order (deterministic).  TI = float: the partial
+// rows themselves (few rows -- the conv kernels keep running sums -- so stage A is skipped).
+template <typename TI>
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const TI* __restrict__ scratch, int chunks, int C, double inv_count,
                                                            double unbias, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ rmean,
                                                            float* __restrict__ rvar, float momentum, float eps,
@@ -112,8 +114,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     for (int t = ty; t < chunks; t += 16) {
-      s1 += scratch[((long)t * 2 + 0) * C + c];
-      s2 += scratch[((long)t * 2 + 1) * C + c];
+      s1 += (double)scratch[((long)t * 2 + 0) * C + c];
+      s2 += (double)scratch[((long)t * 2 + 1) * C + c];
     }
   }
   red[0][ty][tx] = s1;
@@ -343,6 +345,12 @@ extern "C" int sr_bn_finalize(const float* stats, int tiles, int C, int64_t coun
   if (!stats || tiles <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !scale || !shift || !scratch || scratch_rows < 1)
     return SR_ERR_ARG;
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+  if (tiles <= 4096) {              // few partial rows: one kernel, fp64 sums straight from the fp32 rows (<= 256 per thread)
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stats, tiles, C,
+                       1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps, scale, shift);
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+  }
   int chunks = (tiles + 31) / 32;   // stage A: >= 32 partial rows per workgroup, up to 1024 workgroups per 64 channels
   if (chunks > scratch_rows) chunks = scratch_rows;
   if (chunks > 1024) chunks = 1024;
@@ -350,7 +358,7 @@ extern "C" int sr_bn_finalize(const float* stats, int tiles, int C, int64_t coun
   chunks = (tiles + tpc - 1) / tpc;
   hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, stats, tiles, C, tpc,
                      scratch);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, scratch, chunks, C,
+  hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const double*)scratch, chunks, C,
                      1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps, scale, shift);
   SR_CHECK_LAUNCH();
   return SR_OK;
