@@ -1,0 +1,58 @@
+"""Race screen for the pipelined kernels: every launch is repeated and must reproduce its first result BIT FOR BIT (none of
+these kernels uses atomics; a read that beats its DMA, or a DMA that beats a read, shows up as run-to-run differences)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from situation_recognition_amd import ops
+dt, dev = torch.bfloat16, "cuda"
+REP = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+torch.manual_seed(0)
+
+
+def t(*s, scale=1.0):
+    return (torch.randn(*s, device=dev) * scale).to(dt)
+
+
+def flat(r):
+    r = r if isinstance(r, (tuple, list)) else (r,)
+    return [x.clone() for x in r if torch.is_tensor(x)]
+
+
+def screen(name, fn):
+    ref = flat(fn())
+    bad = 0
+    for _ in range(REP):
+        out = flat(fn())
+        bad += int(any(not torch.equal(a, b) for a, b in zip(ref, out)))
+    torch.cuda.synchronize()
+    print("%-44s %3d / %d runs differ" % (name, bad, REP), flush=True)
+    return bad
+
+
+bad = 0
+for B in (96, 768):
+    x256, x1024 = t(B, 14, 14, 256), t(B, 14, 14, 1024)
+    w33, w3, w1 = t(256, 9 * 256, scale=.03), t(1024, 256, scale=.06), t(256, 1024, scale=.03)
+    sc, sh = torch.rand(1024, device=dev), torch.rand(1024, device=dev)
+    bad += screen("B=%d 3x3 256->256 + stats" % B, lambda: ops.conv2d(x256, w33, 256, 3, 1, 1, want_stats=True))
+    bad += screen("B=%d 1x1 256->1024 scale/shift/res/relu" % B, lambda: ops.conv2d(x256, w3, 1024, 1, 1, 0, bias=sh, escale=sc, res=x1024, relu=True))
+    bad += screen("B=%d 1x1 1024->256 + stats" % B, lambda: ops.conv2d(x1024, w1, 256, 1, 1, 0, want_stats=True))
+    bad += screen("B=%d gram 256" % B, lambda: ops.gram(x256.view(-1, 256)))
+    s2, h2 = torch.rand(256, device=dev) + .5, torch.randn(256, device=dev) * .1
+    def fused():
+        y = x256.view(-1, 256).clone()
+        return y, ops.bn_apply_gram(y, s2, h2)
+    bad += screen("B=%d bn_apply+gram 256" % B, fused)
+    x64 = t(B, 56, 56, 64); w64 = t(64, 9 * 64, scale=.05)
+    bad += screen("B=%d 3x3 64->64 (256x64 tiles)" % B, lambda: ops.conv2d(x64, w64, 64, 3, 1, 1, want_stats=True))
+    x128 = t(B, 28, 28, 128); w128 = t(128, 9 * 128, scale=.04)
+    bad += screen("B=%d 3x3 128->128 (256x128 tiles)" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True))
+M = 36864
+n, h, W = t(M, 2048), t(M, 2048), t(2048, 2048, scale=.02)
+U = t(2048, 2048, scale=.02); b1, b2 = torch.randn(2048, device=dev), torch.randn(2048, device=dev)
+bad += screen("GRU gate GEMM 2 pairs sigmoid", lambda: ops.gemm([(n, W), (h, U)], bias=b1, bias2=b2, act=ops.ACT_SIGMOID))
+bad += screen("GRU gate GEMM sigmoid*h", lambda: ops.gemm([(n, W), (h, U)], bias=b1, bias2=b2, act=ops.ACT_SIGMOID_MUL, aux1=h))
+out = torch.zeros(2048, 2048, device=dev)
+bad += screen("TN GEMM 2048x2048 K=36864", lambda: ops.gemm_tn(n, h, out, accumulate=False))
+print("TOTAL differing runs:", bad)
+sys.exit(1 if bad else 0)
