@@ -44,7 +44,8 @@ struct KArgs {
   int stats_nflush;       // partial-statistics rows each workgroup writes (v3 kernels; see SR_STATS_FLUSH)
   const void* zero_page;  // 256 zero bytes (device address of g_zero_page, resolved once on the host)
   void* trash_page;       // sink for out-of-range lanes' stores
-  int debug;  // SR_GEMM_DEBUG bits (diagnostic builds of bench scripts only): 1 = skip MFMA, 2 = skip loads after the prologue
+  int debug;  // SR_GEMM_DEBUG bits (diagnostics, tools/ only): v2: 1 = skip MFMA, 2 = skip loads after the prologue; v3: 4 = in-kernel
+              // stamps (SR_STAMPS builds), 8 = no start offset between the two workgroups of a CU, 32 = lock-step loop instead of ping-pong
 };
 
 template <typename T> struct Frag;  // one 16-byte MFMA operand fragment
