@@ -183,11 +183,22 @@ def build_parser():
     p.add_argument('--steps', type=int, default=4, help='GGNN message-passing steps (reference: 4)')
     p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     p.add_argument('--encoder_file', type=str, default='', help='annotation file the vocabulary is built from (default train.json)')
+    p.add_argument('--shards', type=str, default='', help='directory of pre-decoded uint8 shards (imsitu_shards): one sub-directory '
+                   'per annotation file; decode + resize happen once, crop / flip / normalise on the GPU')
+    p.add_argument('--make_shards', action='store_true', help='write the shards of --train_file/--dev_file/--test_file under --shards and exit')
     return p
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.make_shards:                                  # host-only: decode + resize every image once (no GPU needed)
+        from .imsitu_shards import write_shards
+        for f in (args.train_file, args.dev_file, args.test_file):
+            path = os.path.join(args.dataset_folder, f)
+            if os.path.isfile(path):
+                n = write_shards(args.imgset_dir, list(json.load(open(path))), _shard_dir(args, f), quiet=False)
+                print('{}: {} shards under {}'.format(f, n, _shard_dir(args, f)))
+        return
     rank, world, local = parallel.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("situation_recognition_amd.sr needs an MI355X (no CPU fallback)")
@@ -203,7 +214,7 @@ def main(argv=None):
         encoder = imsitu_encoder(load(args.encoder_file or 'train.json'), quiet=(rank != 0))
         if rank == 0:
             json.dump(encoder.state(), open(cache, 'w'))
-    mk = lambda f, tf, shuffle: _loader(args, load(f), encoder, tf, shuffle, rank, world)
+    mk = lambda f, tf, shuffle: _loader(args, load(f), encoder, tf, shuffle, rank, world, fname=f)
     D = 2048 if args.backbone >= 50 else 512
     model = FCGGNN(encoder, D, steps=args.steps, backbone=args.backbone,
                    dtype=torch.bfloat16 if args.dtype == 'bf16' else torch.float32).to(dev)
@@ -238,7 +249,16 @@ def main(argv=None):
         torch.distributed.destroy_process_group()
 
 
-def _loader(args, ann, encoder, transform, shuffle, rank, world):
+def _shard_dir(args, fname):
+    return os.path.join(args.shards, os.path.splitext(os.path.basename(fname))[0])
+
+
+def _loader(args, ann, encoder, transform, shuffle, rank, world, fname=None):
+    if args.shards and fname is not None and os.path.isfile(os.path.join(_shard_dir(args, fname), "index.json")):
+        from .imsitu_shards import ShardLoader
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        return ShardLoader(_shard_dir(args, fname), ann, encoder, max(1, args.batch_size // world), torch.device("cuda", local),
+                           train=shuffle, rank=rank, world=world)
     ds = imsitu_loader.imsitu_loader(args.imgset_dir, ann, encoder, transform)
     sampler = None
     if world > 1:
