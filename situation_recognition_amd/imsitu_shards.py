@@ -121,11 +121,38 @@ class ShardLoader:
         self.epoch += 1
         if self._gen is None and self.device.type == "cuda":
             self._gen = torch.Generator(device=self.device).manual_seed(self.seed * 7919 + self.rank)
-        for b0 in range(0, len(mine), self.batch_size):
-            ids = mine[b0:b0 + self.batch_size]
-            canvas = self._gather(ids)
+        batches = [mine[b0:b0 + self.batch_size] for b0 in range(0, len(mine), self.batch_size)]
+        for ids, canvas in self._prefetched(batches):
             if self.device.type == "cuda":
-                canvas = canvas.pin_memory().to(self.device, non_blocking=True)
+                canvas = canvas.to(self.device, non_blocking=True)
             t = torch.tensor(ids)
             img = gpu_augment(canvas, self.rects[t].to(self.device), self.train, self._gen)
             yield [self.names[j] for j in ids], img, self.verbs[t], self.labels[t]
+
+    def _prefetched(self, batches, depth=2):
+        """The host side of a batch (gather from the memory-mapped shards into pinned memory: ~1.5 GB at B=6144) runs on a
+        background thread, `depth` batches ahead of the training step that consumes them."""
+        import queue
+        import threading
+        q = queue.Queue(maxsize=depth)
+        pin = self.device.type == "cuda"
+
+        def work():
+            try:
+                for ids in batches:
+                    c = self._gather(ids)
+                    q.put((ids, c.pin_memory() if pin else c))
+                q.put(None)
+            except BaseException as e:           # surface loader errors in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+        th.join()
