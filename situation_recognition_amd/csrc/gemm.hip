@@ -45,7 +45,7 @@ struct KArgs {
   const void* zero_page;  // 256 zero bytes (device address of g_zero_page, resolved once on the host)
   void* trash_page;       // sink for out-of-range lanes' stores
   int debug;  // SR_GEMM_DEBUG bits (diagnostics, tools/ only): v2: 1 = skip MFMA, 2 = skip loads after the prologue; v3: 4 = in-kernel
-              // stamps (SR_STAMPS builds), 8 = no start offset between the two workgroups of a CU, 32 = lock-step loop instead of ping-pong
+              // stamps (SR_STAMPS builds), 32 = lock-step loop instead of ping-pong
 };
 
 template <typename T> struct Frag;  // one 16-byte MFMA operand fragment
@@ -886,23 +886,8 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
 #endif
   };
 
-  // ---------------- phase offset between workgroups ----------------
-  // All workgroups run tiles of equal length, so left alone they compute in lockstep and then ALL store their tiles
-  // at once: HBM idles during the K loops and is oversubscribed during the epilogues (measured: store phase as long
-  // as the K loop on output-heavy shapes).  Starting workgroup g with a delay of (g mod 8)/8 of a tile period keeps
-  // only 1/8 of the chip in its store phase at any time.  Purely a timing nudge: no correctness dependence.
-  if (CFG <= 2 && my_tiles >= 4 && !(p.debug & 8)) {
-    // two workgroups share a CU (second dispatch round = upper half of the grid): offset them by half a tile period so
-    // that one is in its K loop while the other drains its stores
-    const unsigned long long period = (unsigned long long)nkt * 2300ull + 16000ull;   // cycles per tile, roughly
-    // which of the two am I?  The workgroup whose LDS allocation does not start at 0 (HW_REG_LDS_ALLOC.LDS_BASE) is the second
-    // one on its CU -- independent of how the dispatcher numbered us.
-    const unsigned lds_base = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (11 << 11));
-    const unsigned long long delay = lds_base != 0 ? period / 2 : 0;
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t_start < delay) __builtin_amdgcn_s_sleep(32);
-  }
-
+  // (A start offset of half a tile period between the two workgroups of a CU -- so that one drains its stores while the
+  //  other multiplies -- was worth a few percent with the first K loops and costs 2-4 % with this one: removed.)
   // ---------------- K loop ----------------
   // One barrier per step, everything else straight-line:
   //     wait (my pieces of step s) ; barrier ; issue the pieces of step s+D ; read the 12 fragments of step s ; 32 MFMAs
