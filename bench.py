@@ -6,11 +6,13 @@ One "step" = zero_grad -> FCGGNN.forward(img, gt_verb) -> verb_loss + nouns_loss
 all-reduce (N > 1) -> clip_grad_norm_(1) -> Adamax step  (reference order: sr.py:63-83), on synthetic inputs
 already resident in HBM.  Scorer / data loading / .item() logging are outside the step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: one rank per GPU -- under torch.distributed.run when
+                                                                  launched by it, otherwise bench.py starts the ranks itself)
 
 Prints ONE JSON line on rank 0, including
-  roofline     -- the dominant kernel (backbone implicit-GEMM convolution): algorithmic FLOPs per launch / average
-                  launch duration, measured with HIP events on the launch stream, against the dense bf16 MFMA peak;
+  roofline     -- the dominant kernel family (backbone implicit-GEMM convolution): algorithmic FLOPs per launch / average
+                  launch duration, measured with HIP events on the launch stream, against the dense bf16 MFMA peak, plus
+                  `by_kernel`: every kernel family of the step on the roofline that bounds it;
   cpu_baseline -- the CPU oracle (oracle/, "port") timed on the host cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
@@ -109,6 +111,33 @@ def cpu_baseline(args):
                       "batch %d, %d timed steps after 1 warm-up (%.1f s)" % (args.backbone, args.T, B, steps, dt)}
 
 
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves -- as a CHILD process, before
+    this process has touched the GPU (never re-exec a process that initialised HIP) -- and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log("spawning %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def profile_step(step_fn, ops, torch):
+    """One extra training step with every libsrhip launch bracketed by HIP events on its launch stream.
+    Returns {tag: (launches, seconds, algorithmic flops, algorithmic bytes)}."""
+    ops.PROFILE = []
+    step_fn()
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for tag, e0, e1, fl, by in prof:
+        n, t, f, b = agg.get(tag, (0, 0.0, 0.0, 0.0))
+        agg[tag] = (n + 1, t + e0.elapsed_time(e1) * 1e-3, f + fl, b + by)
+    return agg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,11 +148,17 @@ def main():
     ap.add_argument("--T", type=int, default=5)
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--cpu-batch", type=int, default=32)
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--shared-backbone", action="store_true",
+                    help="both backbones start from the SAME weights (what the reference's two pretrained=True loads give, "
+                         "model.py:16,100-101): FCGGNN then runs one train-mode pass for both.  Not the headline configuration.")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
 
     from situation_recognition_amd import ops, parallel
     from situation_recognition_amd.imsitu_encoder import imsitu_encoder
@@ -145,7 +180,10 @@ def main():
     enc = imsitu_encoder.synthetic()                              # V=504, 190 roles, L=2001, R=6
     torch.manual_seed(1238)                                       # identical replicas on every rank
     D = 2048 if args.backbone >= 50 else 512
-    net = FCGGNN(enc, D, steps=args.T, backbone=args.backbone, dtype=dtype).to(dev)
+    net = FCGGNN(enc, D, steps=args.T, backbone=args.backbone, dtype=dtype)
+    if args.shared_backbone:
+        net.convnet_nouns.load_state_dict(net.convnet_verbs.state_dict())
+    net = net.to(dev)
     net.drop_seed_base += rank
     net.train()
     params = [p for p in net.parameters() if p.requires_grad]
@@ -157,12 +195,20 @@ def main():
     img, verb, nouns = synthetic_batch(enc, B, args.res, dev, seed_shift=rank)
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        if bucket is None:
+            opt.zero_grad(set_to_none=True)
+        else:
+            bucket.zero()
         pv, pn, pg = net(img, verb)
-        loss = net.verb_loss(pv, verb) + net.nouns_loss(pn, nouns)
-        loss.backward()
-        if bucket is not None:
-            bucket.reduce()
+        if bucket is None:
+            loss = net.verb_loss(pv, verb) + net.nouns_loss(pn, nouns)
+            loss.backward()
+        else:
+            # loss means over the GLOBAL batch (sr.py:67-76 after DataParallel's gather): per-rank sums over all-reduced
+            # denominators; the gradient buckets are then summed over the ranks, launched from autograd hooks during backward
+            loss = parallel.global_batch_loss(net, pv, pn, verb, nouns)[0]
+            loss.backward()
+            bucket.finish()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
         return loss
@@ -180,11 +226,13 @@ def main():
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = time.perf_counter() - t0
+    final_loss = loss.detach().clone()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
-    final_loss = float(loss.detach())
+        torch.distributed.all_reduce(final_loss)                  # shares of the global-batch loss -> the loss
+    final_loss = float(final_loss)
     log("timed region done: %.1f ms/step" % (1000.0 * elapsed / args.steps))
 
     out = {
@@ -199,24 +247,44 @@ def main():
                                "full training step, global batch %d, %dx%d synthetic images, imSitu-sized vocabulary "
                                "(504 verbs / 190 roles / 2001 labels)" % (args.backbone, args.T, args.global_batch, args.res, args.res),
                    "global_batch": args.global_batch, "per_gpu_batch": B, "parallelism": "dp%d" % world,
+                   "backbone_weights": "shared (one pass serves both)" if args.shared_backbone else "two distinct backbones",
                    "final_loss": round(final_loss, 4)},
     }
 
     if rank == 0 and not args.no_roofline:
-        # Dominant kernel = conv_igemm_* (backbone convolutions).  One extra train-mode backbone pass with every launch
-        # bracketed by HIP events on the launch stream; achieved = sum(ALGORITHMIC FLOPs) / sum(durations)
-        # = (average algorithmic FLOPs per launch) / (average launch duration).  Algorithmic = 2*M*N*K of each convolution
-        # once (= 23.023 GFLOP per image for ResNet-152): the statistics-only launches of the two-launch
-        # BatchNorm scheme add their time but no FLOPs.
-        ops.PROFILE = []
-        net.convnet_verbs(img)
-        torch.cuda.synchronize()
-        prof, ops.PROFILE = ops.PROFILE, None
-        conv = [(e0.elapsed_time(e1) * 1e-3, fl, by) for tag, e0, e1, fl, by in prof if tag == "conv"]
-        tsum, fsum, bsum = sum(c[0] for c in conv), sum(c[1] for c in conv), sum(c[2] for c in conv)
+        # One extra training step, every libsrhip launch bracketed by HIP events on its launch stream (single stream: the
+        # two-stream overlap of small batches is switched off so that a launch's duration is its own).
+        # Headline = the dominant kernel family conv_igemm_* (backbone implicit-GEMM convolutions) on the MFMA roofline,
+        # as SURVEY 8(d) bounds it: achieved = sum of ALGORITHMIC FLOPs (2*M*N*K of each convolution once = 23.023 GFLOP per
+        # image and pass for ResNet-152) / sum of the launches' durations -- statistics-only launches of the two-launch
+        # BatchNorm scheme add their time but no FLOPs.  by_kernel: the same per kernel family, each on the roofline that
+        # bounds it (3x3 and stem convolutions: MFMA; 1x1 convolutions: HBM; GGNN gate GEMMs: MFMA; the GGNN step's non-GEMM
+        # kernels -- aggregate, GRU backward halves -- HBM, bytes as SURVEY 8(d) counts them).
+        keep = net.overlap_backbones
+        net.overlap_backbones = False
+        agg = profile_step(step, ops, torch)
+        net.overlap_backbones = keep
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        ach = fsum / tsum / 1e12
-        hbm_ach = bsum / tsum / 1e9              # algorithmic GB/s: every operand read once, every output written once
+
+        def entry(tags, bound, kernel):
+            n = sum(agg[t][0] for t in tags if t in agg)
+            if n == 0:
+                return None
+            tsum = sum(agg[t][1] for t in tags if t in agg)
+            fsum = sum(agg[t][2] for t in tags if t in agg)
+            bsum = sum(agg[t][3] for t in tags if t in agg)
+            e = {"kernel": kernel, "launches_per_step": n, "avg_launch_ms": round(1e3 * tsum / n, 4), "ms_per_step": round(1e3 * tsum, 2)}
+            if bound == "mfma":
+                e.update(bound="mfma", achieved=round(fsum / tsum / 1e12, 2), peak=peak, unit="TFLOP/s", frac=round(fsum / tsum / 1e12 / peak, 4),
+                         alg_gflop_per_launch=round(fsum / n / 1e9, 3))
+            else:
+                e.update(bound="hbm", achieved=round(bsum / tsum / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(bsum / tsum / 1e9 / PEAK_HBM_GBS, 4),
+                         alg_bytes_per_launch=round(bsum / n))
+            return e
+
+        conv_tags = ["conv1x1", "conv3x3", "conv7x7"]
+        head = entry(conv_tags, "mfma", "conv_igemm_* (backbone implicit-GEMM convolutions, both passes, incl. statistics-only launches)")
+        hbm_view = entry(conv_tags, "hbm", "conv_igemm_*")
         # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately on this exact
         # command: profiles/conv_traffic.json records them with the gfx950 corrections); null for any other configuration
         traffic = None
@@ -227,16 +295,18 @@ def main():
                 traffic = round(t["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
-        # The conv family mixes matrix-bound 3x3 layers with HBM-bound 1x1 layers (expansion + residual, reduce): both
-        # rooflines are reported, the one with the larger fraction -- the one that binds more of the time -- as the headline.
-        mfma = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
-        hbm = {"bound": "hbm", "achieved": round(hbm_ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(hbm_ach / PEAK_HBM_GBS, 4)}
-        first, second = (hbm, mfma) if hbm["frac"] >= mfma["frac"] else (mfma, hbm)
-        out["roofline"] = dict(first, traffic=traffic, other=second,
-                               kernel="conv_igemm_* (backbone implicit-GEMM convolutions, %d launches per pass incl. statistics-only launches)" % len(conv),
-                               avg_launch_ms=round(1e3 * tsum / len(conv), 4),
-                               alg_gflop_per_launch=round(fsum / len(conv) / 1e9, 3),
-                               alg_bytes_per_launch=round(bsum / len(conv)))
+        by = [entry(["conv3x3"], "mfma", "conv_igemm_* 3x3"), entry(["conv1x1"], "hbm", "conv_igemm_* 1x1 (reduce / expansion+residual / downsample)"),
+              entry(["conv7x7"], "mfma", "conv_igemm_* 7x7 stem"),
+              entry(["gram"], "hbm", "gram_kernel (Gram-matrix statistics of the expansion convs, fused with the preceding BN-apply)"),
+              entry(["bn_apply"], "hbm", "bn_apply_kernel"), entry(["maxpool"], "hbm", "maxpool_kernel"),
+              entry(["gemm_gate"], "mfma", "gemm_nt_v3_kernel with GRU gate epilogues (GGNN step: z, r & r*h, candidate & blend)"),
+              entry(["gemm"], "mfma", "gemm_nt_v3_kernel linear (W_p, classifiers, backward data gradients)"),
+              entry(["gemm_tn"], "mfma", "gram_kernel<256,true,true> TN weight gradients"),
+              entry(["aggregate", "gru_bwd"], "hbm", "GGNN step non-GEMM kernels: aggregate_kernel, gru_bwd1/2_kernel (SURVEY 8d: 11*M*D*s per step "
+                                                      "if the forward gates were standalone; they are fused into the gate GEMMs)")]
+        out["roofline"] = dict(head, traffic=traffic, alg_bytes_per_launch=hbm_view["alg_bytes_per_launch"],
+                               hbm_view={k: hbm_view[k] for k in ("achieved", "peak", "unit", "frac")},
+                               by_kernel=[e for e in by if e is not None])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

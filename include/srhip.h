@@ -76,6 +76,10 @@ typedef struct sr_gemm_args {
 } sr_gemm_args;
 int sr_gemm(const sr_gemm_args* a, int dtype, void* stream);
 int sr_gemm_stats_tiles(int M, int N);   /* rows of `stats` sr_gemm / sr_conv2d will write for (M, N) */
+/* Which tile shape sr_gemm / sr_conv2d will run an (M, N) launch on: 4 = 256x256 (8 waves, half-step ping-pong loop),
+ * 2 = 256x128, 1 = 256x64 (4 waves, two workgroups per CU), 0 = the 128-byte-step fallback kernels.  `linear` != 0: epilogue
+ * is SR_ACT_NONE / SR_ACT_RELU.  Introspection for tests and profiles (a parity test states which kernel it covered). */
+int sr_gemm_tile_cfg(int M, int N, int linear, int out_16bit);
 /* Diagnostic only (synchronises!): copies the in-kernel cycle stamps of the last v3 GEMM launched with
  * SR_GEMM_DEBUG=4 to host memory: [256 blocks][8 waves][8] uint64 (0 vmcnt wait, 1 barrier, 2 DMA issue, 3 MFMA, 4 epilogue, 5 steps). */
 int sr_debug_stamps(unsigned long long* host_out, int count);
@@ -119,7 +123,11 @@ int sr_image_prep_u8(const uint8_t* img, void* out, int B, int H0, int W0, int H
  * running-statistics EMA (momentum, unbiased variance).  running_* may be NULL. */
 int sr_bn_finalize(const float* stats, int tiles, int C, int64_t count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps,
-                   float* scale, float* shift, double* scratch, int scratch_rows, void* stream);
+                   float* scale, float* shift, double* scratch, int scratch_rows,
+                   float* running_mean2, float* running_var2, float momentum2, void* stream);
+/* running_mean2 / running_var2 / momentum2 (NULL / 0 when unused): a SECOND BatchNorm that sees the same batch statistics --
+ * FCGGNN's two backbones start from the same pretrained weights (reference model.py:16,100-101) and never train them, so
+ * while they are identical one pass serves both, and the twin's buffers take its own EMA (two passes' worth: model.py:176-178). */
 /* scratch: caller-owned fp64 workspace [scratch_rows][2][C] (scratch_rows >= 1; 1024 rows use full parallelism)
  * for the deterministic two-stage reduction of the partials. */
 
@@ -141,6 +149,7 @@ int sr_bn_apply_gram(void* x, int64_t M, int C, int64_t ldx, int dtype, const fl
 int sr_bn_finalize_gram(const float* partials, int64_t npartials, int C, const void* w, int64_t ldw, int N, int dtype,
                         int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
                         float momentum, float eps, float* scale, float* shift, double* scratch, int64_t scratch_elems,
+                        float* running_mean2, float* running_var2, float momentum2 /* twin BatchNorm, as sr_bn_finalize */,
                         void* stream);
 
 /* y = [relu]( x*scale[c] + shift[c] (+ res) ), rows x C, in place allowed. */
@@ -157,12 +166,18 @@ int sr_avgpool(const void* x, void* y, int B, int HW, int C, int dtype, void* st
  * role_table: int32 [V][R]; feat_relu != 0 applies relu to feat first (unused by the noun path). */
 int sr_node_init_fwd(const void* feat, const float* role_emb, const float* verb_emb, const int64_t* verbs,
                      const int32_t* role_table, void* node, int B, int R, int D, int dtype, void* stream);
-/* gradients of the above into fp32 d_role_emb [NR+1,D] and d_verb_emb [V,D] (atomic adds; the
- * padding row NR receives none, as nn.Embedding(padding_idx) does).  feat gets no gradient
- * (frozen backbone, model.py:17-18). */
+/* gradients of the above: fp32 d_role_emb [NR+1,D] and d_verb_emb [V,D], both written IN FULL (the padding row NR and
+ * the rows of verbs / roles absent from the batch get zeros, as nn.Embedding(padding_idx) does) with a fixed summation
+ * order -- no atomics, bit-reproducible.  The caller supplies the batch grouped by verb and the role table's inverted index:
+ *   order    int32 [B]     image indices sorted (stably) by verb id
+ *   seg      int32 [V+1]   order[seg[v] .. seg[v+1]) are the images of verb v
+ *   inv_ptr  int32 [NR+1], inv_slot int32 [nnz]: inv_slot[inv_ptr[q] .. inv_ptr[q+1]) = the slots v*R+r with role_table[v][r] == q
+ *   scratch  fp32 [V*R*D]  per-(verb, slot) partial sums
+ * feat gets no gradient (frozen backbone, model.py:17-18). */
 int sr_node_init_bwd(const void* dnode, const void* feat, const float* role_emb, const float* verb_emb,
-                     const int64_t* verbs, const int32_t* role_table, float* d_role_emb, float* d_verb_emb,
-                     int B, int R, int D, int NR, int dtype, void* stream);
+                     const int32_t* order, const int32_t* seg, const int32_t* role_table, const int32_t* inv_ptr,
+                     const int32_t* inv_slot, float* scratch, float* d_role_emb, float* d_verb_emb,
+                     int B, int R, int D, int V, int NR, int dtype, void* stream);
 
 /* out[b,i,:] = sum_j A[verb[b]][i][j] * h[b,j,:] (+ add[b,i,:])   (transpose != 0: A^T)
  * The role-graph message step of GGSNN.forward (model.py:66-77) in its algebraic form, with the

@@ -47,20 +47,21 @@ SIGNATURES = {
     "sr_abi_version": [],
     "sr_gemm": [C.POINTER(GemmArgs), _I, _P],
     "sr_gemm_stats_tiles": [_I, _I],
+    "sr_gemm_tile_cfg": [_I, _I, _I, _I],
     "sr_debug_stamps": [_P, _I],
     "sr_conv2d": [C.POINTER(ConvArgs), _I, _P],
     "sr_stem_prep": [_P, _P, _I, _I, _I, _I, _P],
     "sr_image_prep_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _P],
-    "sr_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P],
+    "sr_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P, _F, _P],
     "sr_gram_plan": [_L, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "sr_gram": [_P, _L, _I, _L, _I, _P, _L, _P],
     "sr_bn_apply_gram": [_P, _L, _I, _L, _I, _P, _P, _P, _L, _P],
-    "sr_bn_finalize_gram": [_P, _L, _I, _P, _L, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _P],
+    "sr_bn_finalize_gram": [_P, _L, _I, _P, _L, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _P, _P, _F, _P],
     "sr_bn_apply": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "sr_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P],
     "sr_avgpool": [_P, _P, _I, _I, _I, _I, _P],
     "sr_node_init_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "sr_node_init_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sr_node_init_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sr_ggnn_aggregate": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "sr_gru_bwd1": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "sr_gru_bwd2": [_P, _P, _P, _P, _P, _L, _I, _P],

@@ -16,6 +16,49 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
     if (e_ != hipSuccess) return SR_ERR_LAUNCH;                \
   } while (0)
 
+// ---- per-device host-side caches.  One process normally drives one GPU, but a process that moves on to a second device must
+// not hand the first device's symbol addresses to kernels on the other one, nor assume its kernel attributes were set there.
+constexpr int SR_MAX_DEV = 32;
+inline int sr_cur_dev() {
+  int d = 0;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < SR_MAX_DEV) ? d : -1;
+}
+// device address of a __device__ variable on the CURRENT device (nullptr on failure)
+#define SR_DEVICE_SYMBOL(var)                                                                 \
+  ([]() -> void* {                                                                            \
+    static void* cache_[SR_MAX_DEV] = {};                                                     \
+    const int d_ = sr_cur_dev();                                                              \
+    if (d_ < 0) return nullptr;                                                               \
+    void* p_ = __atomic_load_n(&cache_[d_], __ATOMIC_ACQUIRE);                                \
+    if (!p_) {                                                                                \
+      if (hipGetSymbolAddress(&p_, HIP_SYMBOL(var)) != hipSuccess) p_ = nullptr;              \
+      __atomic_store_n(&cache_[d_], p_, __ATOMIC_RELEASE);                                    \
+    }                                                                                         \
+    return p_;                                                                                \
+  }())
+// hipFuncAttributeMaxDynamicSharedMemorySize, set once per (kernel, device)
+template <auto Kernel>
+inline bool sr_set_dynamic_lds(int bytes) {
+  static unsigned done[SR_MAX_DEV] = {};
+  const int d = sr_cur_dev();
+  if (d < 0) return false;
+  if (__atomic_load_n(&done[d], __ATOMIC_ACQUIRE)) return true;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  __atomic_store_n(&done[d], 1u, __ATOMIC_RELEASE);
+  return true;
+}
+inline int sr_num_cus() {
+  static int cache[SR_MAX_DEV] = {};
+  const int d = sr_cur_dev();
+  if (d < 0) return 256;
+  int n = __atomic_load_n(&cache[d], __ATOMIC_ACQUIRE);
+  if (n <= 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    __atomic_store_n(&cache[d], n, __ATOMIC_RELEASE);
+  }
+  return n;
+}
+
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return (float)v; }

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const TI* __restrict_
                                                            double unbias, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ rmean,
                                                            float* __restrict__ rvar, float momentum, float eps,
-                                                           float* __restrict__ scale, float* __restrict__ shift) {
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ rmean2, float* __restrict__ rvar2, float momentum2) {
   __shared__ double red[2][16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -132,6 +133,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const TI* __restrict_
   shift[c] = beta[c] - (float)mean * sc;
   if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
   if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * unbias);
+  if (rmean2) rmean2[c] = (1.f - momentum2) * rmean2[c] + momentum2 * (float)mean;      // a second BatchNorm fed the same batch
+  if (rvar2) rvar2[c] = (1.f - momentum2) * rvar2[c] + momentum2 * (float)(var * unbias);
 }
 
 // ------------------------------------------------------------------ BN apply
@@ -341,13 +344,15 @@ extern "C" int sr_image_prep_u8(const uint8_t* img, void* out, int B, int H0, in
 
 extern "C" int sr_bn_finalize(const float* stats, int tiles, int C, int64_t count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* scale,
-                              float* shift, double* scratch, int scratch_rows, void* stream) {
+                              float* shift, double* scratch, int scratch_rows, float* running_mean2, float* running_var2,
+                              float momentum2, void* stream) {
   if (!stats || tiles <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !scale || !shift || !scratch || scratch_rows < 1)
     return SR_ERR_ARG;
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   if (tiles <= 4096) {              // few partial rows: one kernel, fp64 sums straight from the fp32 rows (<= 256 per thread)
     hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stats, tiles, C,
-                       1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps, scale, shift);
+                       1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
+                       running_mean2, running_var2, momentum2);
     SR_CHECK_LAUNCH();
     return SR_OK;
   }
@@ -359,7 +364,8 @@ extern "C" int sr_bn_finalize(const float* stats, int tiles, int C, int64_t coun
   hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, stats, tiles, C, tpc,
                      scratch);
   hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const double*)scratch, chunks, C,
-                     1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps, scale, shift);
+                     1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
+                     running_mean2, running_var2, momentum2);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

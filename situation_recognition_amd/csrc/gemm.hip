@@ -1160,20 +1160,11 @@ __global__ __launch_bounds__(v3_threads(CFG), CFG == 8 ? 1 : 2) void gemm_nt_v3_
 template <typename T, typename TO, int CFG, int EPIX>
 __global__ __launch_bounds__(v3_threads(CFG), CFG == 8 ? 1 : 2) void conv_igemm_v3_kernel(const KArgs p) { gemm_body_v3<T, TO, true, CFG, EPIX>(p); }
 
-inline int num_cus() {
-  static const int n = [] {
-    int dev = 0, cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
-    return cu > 0 ? cu : 256;
-  }();
-  return n;
-}
+inline int num_cus() { return sr_num_cus(); }
 
 template <typename T, typename TO, int WM, int WN, int EPI>
 int launch_v2e(const KArgs& k, unsigned grid, size_t lds, hipStream_t st) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<T, TO, WM, WN, EPI>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr != hipSuccess) return SR_ERR_LAUNCH;
+  if (!sr_set_dynamic_lds<&gemm_nt_v2_kernel<T, TO, WM, WN, EPI>>((int)lds)) return SR_ERR_LAUNCH;
   hipLaunchKernelGGL((gemm_nt_v2_kernel<T, TO, WM, WN, EPI>), dim3(grid), dim3(WM * WN * 64), lds, st, k);
   return SR_OK;
 }
@@ -1188,9 +1179,7 @@ int launch_v2(const KArgs& k, hipStream_t st) {
   const unsigned grid = (unsigned)(ntiles < num_cus() ? ntiles : num_cus());
   int rc = SR_OK;
   if (k.cv.on) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v2_kernel<T, TO, WM, WN>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return SR_ERR_LAUNCH;
+    if (!sr_set_dynamic_lds<&conv_igemm_v2_kernel<T, TO, WM, WN>>((int)lds)) return SR_ERR_LAUNCH;
     hipLaunchKernelGGL((conv_igemm_v2_kernel<T, TO, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, st, k);
   } else {
     switch (k.act) {
@@ -1218,9 +1207,7 @@ inline bool use_v3() {
 template <typename T, typename TO, int WN, int EPI>
 int launch_v3e(const KArgs& k, unsigned grid, size_t lds, hipStream_t st) {
   constexpr int NTHR = v3_threads(WN);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v3_kernel<T, TO, WN, EPI>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr != hipSuccess) return SR_ERR_LAUNCH;
+  if (!sr_set_dynamic_lds<&gemm_nt_v3_kernel<T, TO, WN, EPI>>((int)lds)) return SR_ERR_LAUNCH;
   hipLaunchKernelGGL((gemm_nt_v3_kernel<T, TO, WN, EPI>), dim3(grid), dim3(NTHR), lds, st, k);
   return SR_OK;
 }
@@ -1255,14 +1242,10 @@ int launch_v3(const KArgs& k_in, hipStream_t st) {
   int rc = SR_OK;
   if (k.cv.on) {
     if (k.stats) {
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v3_kernel<T, TO, WN, 1>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (attr != hipSuccess) return SR_ERR_LAUNCH;
+      if (!sr_set_dynamic_lds<&conv_igemm_v3_kernel<T, TO, WN, 1>>((int)lds)) return SR_ERR_LAUNCH;
       hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN, 1>), dim3(grid), dim3(NTHR), lds, st, k);
     } else {
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v3_kernel<T, TO, WN, 0>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (attr != hipSuccess) return SR_ERR_LAUNCH;
+      if (!sr_set_dynamic_lds<&conv_igemm_v3_kernel<T, TO, WN, 0>>((int)lds)) return SR_ERR_LAUNCH;
       hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN, 0>), dim3(grid), dim3(NTHR), lds, st, k);
     }
   } else if constexpr (WN <= 2) {
@@ -1330,22 +1313,12 @@ inline int debug_flags() {
   return f;
 }
 
-struct Pages { void* zero; void* trash; };
-inline const Pages& pages() {
-  static const Pages pg = [] {
-    Pages q{nullptr, nullptr};
-    if (hipGetSymbolAddress(&q.zero, HIP_SYMBOL(g_zero_page)) != hipSuccess) q.zero = nullptr;
-    if (hipGetSymbolAddress(&q.trash, HIP_SYMBOL(g_trash_page)) != hipSuccess) q.trash = nullptr;
-    return q;
-  }();
-  return pg;
-}
 
 int dispatch(const KArgs& k_in, int dtype, int out_f32, hipStream_t st) {
   KArgs k = k_in;
   k.debug = debug_flags();
-  k.zero_page = pages().zero;
-  k.trash_page = pages().trash;
+  k.zero_page = SR_DEVICE_SYMBOL(g_zero_page);       // (per device: see common.h)
+  k.trash_page = SR_DEVICE_SYMBOL(g_trash_page);
   if (!k.zero_page || !k.trash_page) return SR_ERR_LAUNCH;
   if (dtype == SR_F32) return launch<float, float>(k, st);
   if (dtype == SR_BF16) return out_f32 ? launch<bf16_t, float>(k, st) : launch<bf16_t, bf16_t>(k, st);
@@ -1370,6 +1343,12 @@ extern "C" int sr_gemm_stats_tiles(int M, int N) {
   // v3: one row per (workgroup column-tile group, flush, wave group): each workgroup keeps running sums over up to
   // SR_STATS_FLUSH of its tiles (all of which cover the same columns)
   return (int)v3_plan(M, N, cfg, true).rows;
+}
+
+extern "C" int sr_gemm_tile_cfg(int M, int N, int linear, int out_16bit) {
+  if (M <= 0 || N <= 0) return SR_ERR_ARG;
+  if ((N & 7) != 0 && out_16bit) return 0;     // (see `launch`: ragged 16-bit outputs take the v2 kernels)
+  return v3_cfg(M, N, linear != 0);
 }
 
 extern "C" int sr_gemm(const sr_gemm_args* a, int dtype, void* stream) {

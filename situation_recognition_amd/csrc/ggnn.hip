@@ -42,39 +42,82 @@ __global__ void node_init_fwd_kernel(const T* __restrict__ feat, const float* __
   }
 }
 
-// y = relu(f*ro*ve):  d ro = g*[y>0]*f*ve ; d ve = sum_r g*[y>0]*f*ro
+// Backward of node init, deterministic (no atomics).  y = relu(f*ro*ve):  d ro = g*[y>0]*f*ve ; d ve = sum_r g*[y>0]*f*ro.
+// Within one verb v the factors ve (and ro of slot r) are constant, so with S[v,r,:] = sum_{b: verb_b = v} g_{b,r}*[y>0]*f_b
+//     d_verb[v] = sum_r ro[rid(v,r)] * S[v,r]          d_role[rid] = sum_{(v,r): rid(v,r) = rid} ve[v] * S[v,r].
+// Phase 1: one wave per (verb, 64 x 16-byte column strip) walks the verb's images in the (stable) sorted order the host hands
+// over and writes S and d_verb; phase 2: one wave per (role, strip) walks the role's (verb, slot) list -- a static inverted
+// index of the encoder's role table.  Every sum has a fixed order: gradients are bit-reproducible (the atomic version was
+// not: ~190 adders per d_role row at batch 6144).
 template <typename T>
-__global__ void node_init_bwd_kernel(const T* __restrict__ dnode, const T* __restrict__ feat,
-                                     const float* __restrict__ role_emb, const float* __restrict__ verb_emb,
-                                     const int64_t* __restrict__ verbs, const int32_t* __restrict__ role_table,
-                                     float* __restrict__ d_role, float* __restrict__ d_verb, int B, int R, int D, int NR) {
+__global__ __launch_bounds__(64) void node_init_bwd1_kernel(const T* __restrict__ dnode, const T* __restrict__ feat,
+                                                            const float* __restrict__ role_emb, const float* __restrict__ verb_emb,
+                                                            const int32_t* __restrict__ order, const int32_t* __restrict__ seg,
+                                                            const int32_t* __restrict__ role_table, float* __restrict__ S,
+                                                            float* __restrict__ d_verb, int R, int D, int NR) {
   constexpr int N = Vec16<T>::N;
-  const int dv = D / N;
-  const long total = (long)B * dv;
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int d = (int)(idx % dv) * N;
-    const long b = idx / dv;
-    const long v = verbs[b];
+  const int v = blockIdx.x;
+  const int d = (blockIdx.y * 64 + threadIdx.x) * N;
+  if (d >= D) return;
+  float ve[N], ro[kMaxR][N], acc[kMaxR][N];
+  int rid[kMaxR];
+#pragma unroll
+  for (int k = 0; k < N; ++k) ve[k] = verb_emb[(long)v * D + d + k];
+#pragma unroll
+  for (int r = 0; r < kMaxR; ++r) {
+    rid[r] = r < R ? role_table[v * R + r] : NR;
+#pragma unroll
+    for (int k = 0; k < N; ++k) { ro[r][k] = rid[r] != NR ? role_emb[(long)rid[r] * D + d + k] : 0.f; acc[r][k] = 0.f; }
+  }
+  for (int i = seg[v]; i < seg[v + 1]; ++i) {
+    const long b = order[i];
     Vec16<T> f = ld16<T>(feat + b * D + d);
-    float fx[N], ve[N], dve[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) { fx[k] = f.get(k); ve[k] = verb_emb[v * D + d + k]; dve[k] = 0.f; }
-    for (int r = 0; r < R; ++r) {
-      const long rid = role_table[v * R + r];
-      if (rid == NR) continue;  // padding_idx row: value 0, no gradient
-      Vec16<T> g = ld16<T>(dnode + (b * R + r) * D + d);
+    for (int r = 0; r < kMaxR; ++r) {
+      if (r < R && rid[r] != NR) {
+        Vec16<T> g = ld16<T>(dnode + (b * R + r) * D + d);
 #pragma unroll
-      for (int k = 0; k < N; ++k) {
-        const float ro = role_emb[rid * D + d + k];
-        const float pre = fx[k] * ro * ve[k];
-        const float gg = pre > 0.f ? g.get(k) : 0.f;
-        dve[k] += gg * fx[k] * ro;
-        atomicAdd(d_role + rid * D + d + k, gg * fx[k] * ve[k]);
+        for (int k = 0; k < N; ++k) {
+          const float fx = f.get(k);
+          const float pre = fx * ro[r][k] * ve[k];
+          acc[r][k] += pre > 0.f ? g.get(k) * fx : 0.f;
+        }
       }
     }
-#pragma unroll
-    for (int k = 0; k < N; ++k) atomicAdd(d_verb + v * D + d + k, dve[k]);
   }
+  float dve[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) dve[k] = 0.f;
+#pragma unroll
+  for (int r = 0; r < kMaxR; ++r) {
+    if (r < R) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        dve[k] += acc[r][k] * ro[r][k];
+        S[((long)v * R + r) * D + d + k] = acc[r][k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) d_verb[(long)v * D + d + k] = dve[k];
+}
+
+__global__ __launch_bounds__(64) void node_init_bwd2_kernel(const float* __restrict__ S, const float* __restrict__ verb_emb,
+                                                            const int32_t* __restrict__ inv_ptr, const int32_t* __restrict__ inv_slot,
+                                                            float* __restrict__ d_role, int R, int D, int NR) {
+  const int rid = blockIdx.x;
+  const int d = (blockIdx.y * 64 + threadIdx.x) * 4;
+  if (d >= D) return;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rid < NR) {                                   // (row NR = padding_idx: stays zero)
+    for (int e = inv_ptr[rid]; e < inv_ptr[rid + 1]; ++e) {
+      const int slot = inv_slot[e];                 // v * R + r
+      const float4 s = *reinterpret_cast<const float4*>(S + (long)slot * D + d);
+      const float4 w = *reinterpret_cast<const float4*>(verb_emb + (long)(slot / R) * D + d);
+      a.x += s.x * w.x; a.y += s.y * w.y; a.z += s.z * w.z; a.w += s.w * w.w;
+    }
+  }
+  *reinterpret_cast<float4*>(d_role + (long)rid * D + d) = a;
 }
 
 // out[b,i,:] = sum_j A[i][j] h[b,j,:] (+ add).  One workgroup = one image: the R x R adjacency of
@@ -198,17 +241,21 @@ extern "C" int sr_node_init_fwd(const void* feat, const float* role_emb, const f
 }
 
 extern "C" int sr_node_init_bwd(const void* dnode, const void* feat, const float* role_emb, const float* verb_emb,
-                                const int64_t* verbs, const int32_t* role_table, float* d_role_emb, float* d_verb_emb,
-                                int B, int R, int D, int NR, int dtype, void* stream) {
-  if (!dnode || !feat || !role_emb || !verb_emb || !verbs || !role_table || !d_role_emb || !d_verb_emb || B <= 0 || R <= 0 ||
-      D <= 0)
+                                const int32_t* order, const int32_t* seg, const int32_t* role_table, const int32_t* inv_ptr,
+                                const int32_t* inv_slot, float* scratch, float* d_role_emb, float* d_verb_emb, int B, int R, int D,
+                                int V, int NR, int dtype, void* stream) {
+  if (!dnode || !feat || !role_emb || !verb_emb || !order || !seg || !role_table || !inv_ptr || !inv_slot || !scratch ||
+      !d_role_emb || !d_verb_emb || B <= 0 || R <= 0 || R > kMaxR || D <= 0 || V <= 0 || NR < 0)
     return SR_ERR_ARG;
   const int n = dtype == SR_F32 ? 4 : 8;
-  if (D % n) return SR_ERR_ARG;
-  const long total = (long)B * (D / n);
-  DT_SWITCH(dtype, hipLaunchKernelGGL(node_init_bwd_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
-                                      (const T*)dnode, (const T*)feat, role_emb, verb_emb, verbs, role_table, d_role_emb,
-                                      d_verb_emb, B, R, D, NR));
+  if (D % n || D % 4) return SR_ERR_ARG;
+  const unsigned gy1 = (unsigned)((D / n + 63) / 64), gy2 = (unsigned)((D / 4 + 63) / 64);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(node_init_bwd1_kernel<T>, dim3((unsigned)V, gy1), dim3(64), 0, (hipStream_t)stream,
+                                      (const T*)dnode, (const T*)feat, role_emb, verb_emb, order, seg, role_table, scratch,
+                                      d_verb_emb, R, D, NR));
+  SR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(node_init_bwd2_kernel, dim3((unsigned)NR + 1, gy2), dim3(64), 0, (hipStream_t)stream, scratch, verb_emb,
+                     inv_ptr, inv_slot, d_role_emb, R, D, NR);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

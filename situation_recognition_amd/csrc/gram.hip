@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void gram_project_kernel(const double* __restr
                                                            double unbias, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ rmean,
                                                            float* __restrict__ rvar, float momentum, float eps,
-                                                           float* __restrict__ scale, float* __restrict__ shift) {
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ rmean2, float* __restrict__ rvar2, float momentum2) {
   __shared__ double wl[512][8];
   __shared__ double red[2][4][8];
   const int n0 = blockIdx.x * 8, tid = threadIdx.x;
@@ -335,17 +336,11 @@ __global__ __launch_bounds__(256) void gram_project_kernel(const double* __restr
   shift[c] = beta[c] - (float)mean * sc;
   if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
   if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * unbias);
+  if (rmean2) rmean2[c] = (1.f - momentum2) * rmean2[c] + momentum2 * (float)mean;      // a second BatchNorm fed the same batch
+  if (rvar2) rvar2[c] = (1.f - momentum2) * rvar2[c] + momentum2 * (float)(var * unbias);
 }
 
-int gram_cus() {
-  static int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    return v;
-  }();
-  return n;
-}
+int gram_cus() { return sr_num_cus(); }   // (per device: common.h)
 
 struct GramPlan { int P, KS, npan; long rows_per_wg, nslices, npartials; };
 
@@ -370,11 +365,7 @@ bool gram_plan(int64_t M, int C, GramPlan* g) {
 template <int P, bool TWO, bool FUSE = false>
 int gram_launch(const GramArgs& a, const GramPlan& g, hipStream_t st) {
   constexpr int LDS = 131072 + (FUSE ? 2 * P * 4 : 0);
-  static bool once = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_kernel<P, TWO, false, FUSE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
-  }();
-  if (!once) return SR_ERR_LAUNCH;
+  if (!sr_set_dynamic_lds<&gram_kernel<P, TWO, false, FUSE>>(LDS)) return SR_ERR_LAUNCH;
   hipLaunchKernelGGL((gram_kernel<P, TWO, false, FUSE>), dim3((unsigned)(g.nslices * g.npan * g.npan)), dim3(512), LDS, st, a);
   return SR_OK;
 }
@@ -415,16 +406,10 @@ extern "C" int sr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
       ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)out & 15) || ((uintptr_t)scratch & 15) ||
       scratch_floats < (int64_t)ns * N1 * N2)
     return SR_ERR_ARG;
-  static const void* zero = [] {
-    void* z = nullptr;
-    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_gram_zero)) != hipSuccess) z = nullptr;
-    return (const void*)z;
-  }();
+  const void* zero = SR_DEVICE_SYMBOL(g_gram_zero);
   if (!zero) return SR_ERR_LAUNCH;
   constexpr int LDS = 131072;
-  static const bool once = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_kernel<256, true, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
-  if (!once) return SR_ERR_LAUNCH;
+  if (!sr_set_dynamic_lds<&gram_kernel<256, true, true>>(LDS)) return SR_ERR_LAUNCH;
   // the kernel stores block (a, b) transposed -- rows from panel B, four consecutive columns of panel A per lane -- so the
   // matrix whose columns index out's COLUMNS goes in as panel A:  panel A = B (N2), panel B = A (N1)
   GramArgs a{};
@@ -457,11 +442,7 @@ extern "C" int sr_gram(const void* x, int64_t M, int C, int64_t ldx, int dtype, 
   if (dtype != SR_BF16 || !x || !partials || !gram_plan(M, C, &g) || npartials != g.npartials || ldx < C || (ldx & 7) ||
       ((uintptr_t)x & 15) || ((uintptr_t)partials & 15))
     return SR_ERR_ARG;
-  static const void* zero = [] {
-    void* z = nullptr;
-    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_gram_zero)) != hipSuccess) z = nullptr;
-    return (const void*)z;
-  }();
+  const void* zero = SR_DEVICE_SYMBOL(g_gram_zero);
   if (!zero) return SR_ERR_LAUNCH;
   GramArgs a;
   a.x = (const bf16_t*)x; a.M = M; a.ldx = ldx; a.C = C; a.partials = partials; a.pstride = (long)C * C + C;
@@ -488,16 +469,8 @@ extern "C" int sr_bn_apply_gram(void* x, int64_t M, int C, int64_t ldx, int dtyp
   if (dtype != SR_BF16 || !x || !partials || !scale || !shift || !gram_plan(M, C, &g) || g.npan != 1 || npartials != g.npartials ||
       ldx < C || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)partials & 15))
     return SR_ERR_ARG;
-  static const void* zero = [] {
-    void* z = nullptr;
-    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_gram_zero)) != hipSuccess) z = nullptr;
-    return (const void*)z;
-  }();
-  static void* trash = [] {
-    void* z = nullptr;
-    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_gram_trash)) != hipSuccess) z = nullptr;
-    return z;
-  }();
+  const void* zero = SR_DEVICE_SYMBOL(g_gram_zero);
+  void* trash = SR_DEVICE_SYMBOL(g_gram_trash);
   if (!zero || !trash) return SR_ERR_LAUNCH;
   GramArgs a{};
   a.x = (const bf16_t*)x; a.M = M; a.ldx = ldx; a.C = C; a.partials = partials; a.pstride = (long)C * C + C;
@@ -517,7 +490,7 @@ extern "C" int sr_bn_apply_gram(void* x, int64_t M, int C, int64_t ldx, int dtyp
 extern "C" int sr_bn_finalize_gram(const float* partials, int64_t npartials, int C, const void* w, int64_t ldw, int N, int dtype,
                                    int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    float momentum, float eps, float* scale, float* shift, double* scratch, int64_t scratch_elems,
-                                   void* stream) {
+                                   float* running_mean2, float* running_var2, float momentum2, void* stream) {
   if (dtype != SR_BF16 || !partials || npartials <= 0 || !w || N <= 0 || ldw < C || count <= 0 || !gamma || !beta || !scale || !shift ||
       !scratch || (C != 64 && C != 128 && C != 256 && C != 512))
     return SR_ERR_ARG;
@@ -535,7 +508,7 @@ extern "C" int sr_bn_finalize_gram(const float* partials, int64_t npartials, int
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   hipLaunchKernelGGL(gram_project_kernel, dim3((N + 7) / 8), dim3(256), 0, st, (const double*)scratch, (const double*)(scratch + (long)C * C),
                      (const bf16_t*)w, (long)ldw, C, N, 1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps,
-                     scale, shift);
+                     scale, shift, running_mean2, running_var2, momentum2);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }

@@ -16,6 +16,7 @@ class imsitu_scorer:
     def __init__(self, encoder, topk, nref):
         self.encoder, self.topk, self.nref = encoder, topk, nref
         self._cards = []          # list of [B, nkeys] uint8 tensors (device)
+        self._reduced = None      # (sums, total) over all ranks after all_reduce_()
 
     @property
     def keys(self):
@@ -43,6 +44,7 @@ class imsitu_scorer:
             gh = self._hits(top_g, gold, valid)[:, 0]
             cols += [gh > 0, gh >= counts]
         self._cards.append(torch.stack(cols, 1).to(torch.uint8))
+        self._reduced = None
 
     @property
     def score_cards(self):
@@ -53,8 +55,23 @@ class imsitu_scorer:
                 out.append({key: (1 if v else 0.0) for key, v in zip(self.keys, row)})
         return out
 
+    def _totals(self):
+        if self._cards:
+            allc = torch.cat(self._cards, 0)
+            return allc.sum(0, dtype=torch.int64).cpu().tolist(), allc.shape[0]
+        return [0] * len(self.keys), 0
+
+    def all_reduce_(self, group=None):
+        """Data-parallel evaluation: add the other ranks' card sums and sample counts (exact integers), so that
+        `get_average_results_both` returns the metric of the whole set on every rank."""
+        import torch.distributed as dist
+        sums, total = self._totals()
+        t = torch.tensor(sums + [total], dtype=torch.int64)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, group=group)
+        self._reduced = (t[:-1].tolist(), int(t[-1]))
+
     def get_average_results_both(self):
-        allc = torch.cat(self._cards, 0)
-        total = allc.shape[0]
-        sums = allc.sum(0, dtype=torch.int64).cpu().tolist()          # exact integer counts, then one division (as the reference)
+        sums, total = getattr(self, "_reduced", None) or self._totals()   # exact integer counts, then one division (as the reference)
         return {key: v / total for key, v in zip(self.keys, sums)}

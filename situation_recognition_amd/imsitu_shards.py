@@ -83,7 +83,12 @@ def gpu_augment(canvas_u8, rects, train, generator=None):
 class ShardLoader:
     """Iterable with the item layout of the reference's DataLoader over imsitu_loader: (names, img, verb, labels) per batch, with
     img = augmented uint8 NHWC [B,224,224,3] already on `device`.  One rank's share of every (shuffled) epoch under
-    torch.distributed-style sharding: samples rank, rank+world, ... of the epoch's permutation."""
+    torch.distributed-style sharding: samples rank, rank+world, ... of the epoch's permutation.
+
+    train=True: every rank gets the SAME number of samples (the permutation is padded by wrapping, as
+    torch's DistributedSampler does), hence the same number of batches -- each training batch ends in a gradient all-reduce,
+    and a rank with one batch more than its peers would wait in it forever.  train=False (evaluation: no collective inside
+    the loop): no padding, every sample is seen exactly once across the ranks (sr.eval reduces sums and counts afterwards)."""
 
     def __init__(self, shard_dir, annotations, encoder, batch_size, device, train, rank=0, world=1, seed=0):
         with open(os.path.join(shard_dir, "index.json")) as f:
@@ -103,9 +108,18 @@ class ShardLoader:
         self.rank, self.world, self.seed, self.epoch = rank, world, seed, 0
         self._gen = None
 
+    def _per_rank(self):
+        n = len(self.names)
+        if self.train:
+            return (n + self.world - 1) // self.world                          # padded: equal on every rank
+        return (n - self.rank + self.world - 1) // self.world
+
     def __len__(self):
-        mine = (len(self.names) - self.rank + self.world - 1) // self.world
-        return (mine + self.batch_size - 1) // self.batch_size
+        return (self._per_rank() + self.batch_size - 1) // self.batch_size
+
+    def set_epoch(self, epoch):
+        """Same contract as DistributedSampler.set_epoch: the permutation of the next iteration."""
+        self.epoch = int(epoch)
 
     def _gather(self, ids):
         buf = np.empty((len(ids), CANVAS, CANVAS, 3), dtype=np.uint8)
@@ -117,7 +131,10 @@ class ShardLoader:
     def __iter__(self):
         g = torch.Generator().manual_seed(self.seed + self.epoch)
         order = torch.randperm(len(self.names), generator=g) if self.train else torch.arange(len(self.names))
+        if self.train and len(order) % self.world:
+            order = torch.cat([order, order[: self.world - len(order) % self.world]])      # pad by wrapping
         mine = order[self.rank::self.world].tolist()
+        assert len(mine) == self._per_rank()
         self.epoch += 1
         if self._gen is None and self.device.type == "cuda":
             self._gen = torch.Generator(device=self.device).manual_seed(self.seed * 7919 + self.rank)

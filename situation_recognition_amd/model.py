@@ -197,6 +197,7 @@ class resnet(nn.Module):
         self._pending_tracked = 0      # num_batches_tracked increments not yet written to the buffers
         self._gram_stash = None        # (data_ptr, Gram partials) a fused BN-apply left for the expansion conv that follows
         self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_counters())
+        self.register_load_state_dict_post_hook(lambda m, incompatible: m._after_load())
 
     # -- bookkeeping
     def _flush_counters(self):
@@ -206,6 +207,25 @@ class resnet(nn.Module):
                     if isinstance(m, nn.BatchNorm2d):
                         m.num_batches_tracked += self._pending_tracked
             self._pending_tracked = 0
+
+    def _after_load(self):
+        """load_state_dict replaced weights and counters: captured graphs hold folded packs of the OLD weights, and
+        increments recorded before the load must not be added on top of the loaded num_batches_tracked."""
+        self._graphs.clear()
+        self._pending_tracked = 0
+        self._stats_epoch += 1
+
+    def _apply(self, fn, *a, **kw):                     # .to() / .cuda() / .float(): parameters move, captured graphs do not
+        self._graphs.clear()
+        return super()._apply(fn, *a, **kw)
+
+    def _weights_signature(self):
+        """Changes whenever any backbone parameter or buffer is modified in place or replaced (sum of tensor versions +
+        storage addresses): the key of the captured graphs, whose folded weight packs are baked in."""
+        v = 0
+        for t in itertools.chain(self.model.parameters(), self.model.buffers()):
+            v += t._version + (t.data_ptr() & 0xffffffff)
+        return v
 
     def _plan(self):
         if self._units is None:
@@ -229,8 +249,9 @@ class resnet(nn.Module):
                 and u.cin_p in (64, 128, 256, 512) and u.cout_p >= 4 * u.cin_p
                 and n_pixels >= 256 * u.cin_p)    # (below ~256*C pixels the fixed cost of the fp64 finalize loses to launch 1)
 
-    def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False, then=None):
-        """`then`: the unit that consumes this one's output next (lets BN-apply and the consumer's Gram pass share one sweep)."""
+    def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False, then=None, twin=None):
+        """`then`: the unit that consumes this one's output next (lets BN-apply and the consumer's Gram pass share one sweep).
+        `twin` = (unit of a weight-identical backbone, its momentum): its running statistics are updated from the same batch."""
         dt = self.dtype
         if not train:
             w, b = u.folded(dt, self._stats_epoch)
@@ -238,6 +259,16 @@ class resnet(nn.Module):
             return ops.maxpool3x3s2(y) if pool_after else y
         w, gamma, beta = u.raw(dt)
         rm, rv, padded = u.running()
+        tw = None
+        if twin is not None:
+            trm, trv, _ = twin[0].running()
+            tw = (trm, trv, twin[1])
+
+        def done():                                     # channel-padded test nets: copy the updated statistics home
+            if padded:
+                u.writeback(rm, rv)
+                if twin is not None:
+                    twin[0].writeback(tw[0], tw[1])
         if self.two_pass and u.k == 1 and u.cout_p >= 2 * u.cin_p and u.cout_p > 128 and not pool_after:
             # Output-heavy 1x1 conv (bottleneck expansion / downsample): launch it twice instead of conv -> raw tensor ->
             # elementwise pass.  Launch 1 only produces the batch statistics (nothing is written); launch 2 recomputes the
@@ -250,17 +281,15 @@ class resnet(nn.Module):
                 stash, self._gram_stash = self._gram_stash, None
                 part = stash[1] if stash is not None and stash[0] == x.data_ptr() else ops.gram(x.view(-1, u.cin_p))
                 scale, shift = ops.bn_finalize_gram(part, w.view(u.cout_p, u.cin_p), x.shape[0] * Ho * Wo, gamma, beta, rm, rv,
-                                                    momentum, u.bn.eps)
+                                                    momentum, u.bn.eps, twin=tw)
             else:
                 st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, stats_only=True)
-                scale, shift = ops.bn_finalize(st, x.shape[0] * Ho * Wo, gamma, beta, rm, rv, momentum, u.bn.eps)
-            if padded:
-                u.writeback(rm, rv)
+                scale, shift = ops.bn_finalize(st, x.shape[0] * Ho * Wo, gamma, beta, rm, rv, momentum, u.bn.eps, twin=tw)
+            done()
             return ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=shift, escale=scale, res=res, relu=relu)
         y, st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, want_stats=True, stem_hw=stem_hw)
-        scale, shift = ops.bn_finalize(st, y.numel() // u.cout_p, gamma, beta, rm, rv, momentum, u.bn.eps)
-        if padded:
-            u.writeback(rm, rv)
+        scale, shift = ops.bn_finalize(st, y.numel() // u.cout_p, gamma, beta, rm, rv, momentum, u.bn.eps, twin=tw)
+        done()
         if pool_after:                                  # BN + ReLU applied inside the pooling window
             return ops.maxpool3x3s2(y, scale, shift)
         if (then is not None and relu and res is None and u.cout_p <= 256 and then.cin_p == u.cout_p
@@ -271,18 +300,35 @@ class resnet(nn.Module):
             return y
         return ops.bn_apply(y, scale, shift, res=res, relu=relu, out=y)
 
-    def forward(self, x, bn_updates=1):
+    def forward(self, x, bn_updates=1, twin=None, twin_updates=0):
         """`bn_updates`=2 gives the running-statistics state of two consecutive train-mode passes over the
-        same batch in one pass (FCGGNN.forward runs convnet_nouns twice on the same images, model.py:176-178)."""
+        same batch in one pass (FCGGNN.forward runs convnet_nouns twice on the same images, model.py:176-178).
+        `twin`: a second `resnet` with IDENTICAL weights (train mode only): its BatchNorm buffers receive `twin_updates`
+        passes' worth of the same batch statistics, so this one pass stands for the twin's passes too."""
         if self.use_graphs and not self.training and x.is_cuda:
             return self._graph_forward(x)
-        return self._forward_impl(x, bn_updates)
+        return self._forward_impl(x, bn_updates, twin, twin_updates)
+
+    def weights_equal(self, other):
+        """Are all convolution / BatchNorm affine parameters of the two backbones identical?  (The reference loads the same
+        `pretrained=True` weights into both, model.py:16,100-101, and freezes them, model.py:17-18.)  Cached on the
+        parameters' versions and addresses: the comparison itself runs once."""
+        mine, theirs = list(self.model.parameters()), list(other.model.parameters())
+        key = (id(other), tuple((t._version, t.data_ptr()) for t in mine), tuple((t._version, t.data_ptr()) for t in theirs))
+        hit = getattr(self, "_equal_cache", None)
+        if hit is None or hit[0] != key:
+            same = (self.depth == other.depth and self.dtype == other.dtype and len(mine) == len(theirs)
+                    and all(a.shape == b.shape and a.device == b.device for a, b in zip(mine, theirs)))
+            if same:
+                with torch.no_grad():
+                    same = not bool(torch.stack([(a != b).any() for a, b in zip(mine, theirs)]).any().item())
+            hit = self._equal_cache = (key, same)
+        return hit[1]
 
     # -- eval-mode pass replayed from a hipGraph (single-image inference is launch-bound: ~320 kernel launches of a few
     #    microseconds each; one graph launch replaces them)
     def _graph_forward(self, x):
-        w = self.model.conv1.weight
-        key = (tuple(x.shape), self.dtype, w.data_ptr(), w._version, self._stats_epoch)
+        key = (tuple(x.shape), x.dtype, self.dtype, self._weights_signature(), self._stats_epoch)
         hit = self._graphs.get(key)
         if hit is None:
             self._forward_impl(x, 1)                        # eager warm-up: builds the folded packs, sets kernel attributes
@@ -299,7 +345,7 @@ class resnet(nn.Module):
         g.replay()
         return static_out.clone()
 
-    def _forward_impl(self, x, bn_updates=1):
+    def _forward_impl(self, x, bn_updates=1, twin=None, twin_updates=0):
         if not x.is_cuda:
             raise SrError("situation_recognition_amd.resnet runs on an MI355X only (got a CPU tensor; no CPU fallback)")
         u8 = x.dtype == torch.uint8
@@ -310,6 +356,13 @@ class resnet(nn.Module):
         bn0 = self.model.bn1
         m = bn0.momentum if bn0.momentum is not None else 0.1
         momentum = 1.0 - (1.0 - m) ** bn_updates
+        if twin is not None and not (train and twin.training and twin_updates > 0):
+            raise SrError("a twin backbone is only meaningful in train mode (eval folds each backbone's own running statistics)")
+        tstem, tblocks, tm = None, None, 0.0
+        if twin is not None:
+            tstem, tblocks = twin._plan()
+            tm = 1.0 - (1.0 - m) ** twin_updates
+        T = lambda tu: None if twin is None else (tu, tm)
         with torch.no_grad():
             if u8:      # decoded images: ToTensor + Normalize fused into the stem's layout kernel (no fp32 batch)
                 H, W = x.shape[1], x.shape[2]
@@ -317,17 +370,21 @@ class resnet(nn.Module):
             else:
                 H, W = x.shape[2], x.shape[3]
                 xp = ops.stem_prep(x.float().contiguous(), self.dtype)
-            a = self._unit(xp, stem, train, momentum, relu=True, stem_hw=(H, W), pool_after=True)
-            for convs, ds in blocks:
-                idn = a if ds is None else self._unit(a, ds, train, momentum, relu=False)
+            a = self._unit(xp, stem, train, momentum, relu=True, stem_hw=(H, W), pool_after=True, twin=T(tstem))
+            for bi, (convs, ds) in enumerate(blocks):
+                tconvs, tds = tblocks[bi] if twin is not None else ([None] * len(convs), None)
+                idn = a if ds is None else self._unit(a, ds, train, momentum, relu=False, twin=T(tds))
                 y = a
                 for i, u in enumerate(convs[:-1]):
-                    y = self._unit(y, u, train, momentum, relu=True, then=convs[i + 1] if i + 2 == len(convs) else None)
-                a = self._unit(y, convs[-1], train, momentum, relu=True, res=idn)
+                    y = self._unit(y, u, train, momentum, relu=True, then=convs[i + 1] if i + 2 == len(convs) else None, twin=T(tconvs[i]))
+                a = self._unit(y, convs[-1], train, momentum, relu=True, res=idn, twin=T(tconvs[-1]))
             feat = ops.avgpool(a)
         if train:
             self._stats_epoch += 1
             self._pending_tracked += bn_updates
+            if twin is not None:
+                twin._stats_epoch += 1
+                twin._pending_tracked += twin_updates
         return feat[:, : self.out_features] if feat.shape[1] != self.out_features else feat
 
 
@@ -504,7 +561,7 @@ class _NodeInitFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dnode):
         feat, role_w, verb_w, verbs, role_table = ctx.saved_tensors
-        d_role, d_verb = torch.zeros_like(role_w), torch.zeros_like(verb_w)
+        d_role, d_verb = torch.empty_like(role_w), torch.empty_like(verb_w)     # written in full, fixed summation order
         dnode = dnode.contiguous()
         if dnode.dtype != feat.dtype:
             dnode = ops.cast(dnode, feat.dtype)
@@ -586,6 +643,8 @@ class FCGGNN(nn.Module):
         self.overlap_backbones = None if env is None else env not in ("0", "")
         self._side_streams = {}
         self._noun_feat_cache = None
+        # one train-mode pass for both backbones while their (frozen) weights are identical -- see forward()
+        self.share_identical_backbones = os.environ.get("SR_SHARE_BACKBONES", "1") not in ("0", "")
 
     def enable_graphs(self, on=True):
         """Replay the eval-mode backbone passes from captured hipGraphs (latency path for single-image inference)."""
@@ -620,15 +679,23 @@ class FCGGNN(nn.Module):
         feat = self.convnet_nouns(img)
         return self._nouns_from_features(feat, gt_verb, batch_size)
 
-    def predict_verb(self, img, batch_size):                                            # model.py:158-168
-        feat = self.convnet_verbs(img)
+    def _verb_from_features(self, feat, batch_size):
         out = self.ggsnn.run(feat.reshape(batch_size, -1), None, None, 1, True)
         return self._classify(self.verb_classifier, out)
+
+    def predict_verb(self, img, batch_size):                                            # model.py:158-168
+        return self._verb_from_features(self.convnet_verbs(img), batch_size)
 
     def forward(self, img, gt_verb):                                                    # model.py:172-180
         batch_size = img.size(0)
         overlap = self.overlap_backbones if self.overlap_backbones is not None else batch_size <= 4096
-        if overlap and img.is_cuda:
+        if self.share_identical_backbones and self.training and img.is_cuda and self.convnet_verbs.weights_equal(self.convnet_nouns):
+            # Both backbones still hold the SAME frozen weights (what the reference's two `pretrained=True` loads give) and
+            # train-mode BatchNorm ignores the running statistics: their features are identical, so ONE pass serves the verb
+            # path and both noun branches.  The noun backbone's BatchNorm buffers still receive their two updates.
+            feat = self.convnet_verbs(img, bn_updates=1, twin=self.convnet_nouns, twin_updates=2)
+            pred_verb = self._verb_from_features(feat, batch_size)
+        elif overlap and img.is_cuda:
             # The two backbones are independent: the noun backbone runs on a second HIP stream beside the verb path.  Every
             # conv launch is a persistent grid of one workgroup per CU, so the other stream's workgroups move in as a
             # kernel's last round of tiles drains, and its elementwise kernels fill the gaps between launches.
@@ -650,13 +717,22 @@ class FCGGNN(nn.Module):
         gt_pred_nouns = self._nouns_from_features(feat, gt_verb, batch_size)
         return pred_verb, pred_nouns, gt_pred_nouns
 
-    def verb_loss(self, pred_verb, gt_verb):                                            # model.py:183-187
-        return nn.functional.cross_entropy(pred_verb.float(), gt_verb)
+    def verb_loss(self, pred_verb, gt_verb, denom=None):                                # model.py:183-187
+        """`denom` (data parallel, see parallel.global_batch_loss): divide the SUM of this rank's terms by the global batch size
+        instead of taking the rank-local mean."""
+        if denom is None:
+            return nn.functional.cross_entropy(pred_verb.float(), gt_verb)
+        return nn.functional.cross_entropy(pred_verb.float(), gt_verb, reduction="sum") / denom
 
-    def nouns_loss(self, pred_nouns, gt_nouns):                                         # model.py:190-201
+    def nouns_loss(self, pred_nouns, gt_nouns, denoms=None):                            # model.py:190-201
+        """`denoms` [3] (data parallel): the global numbers of non-ignored targets per annotator; each term is then this rank's
+        SUM over its targets divided by the global count (a rank without valid targets contributes exactly 0)."""
         L = self.encoder.get_num_labels()
         logits = pred_nouns.float().transpose(1, 2)
         loss = 0
         for i in range(3):
-            loss = loss + nn.functional.cross_entropy(logits, gt_nouns[:, i], ignore_index=L)
+            if denoms is None:
+                loss = loss + nn.functional.cross_entropy(logits, gt_nouns[:, i], ignore_index=L)
+            else:
+                loss = loss + nn.functional.cross_entropy(logits, gt_nouns[:, i], ignore_index=L, reduction="sum") / denoms[i]
         return loss

@@ -70,7 +70,8 @@ def gemm(pairs, N=None, bias=None, bias_scale=1.0, bias2=None, act=ACT_NONE, res
     a.res, a.ldres = ptr(res), (res.stride(0) if res is not None else 0)
     a.aux1, a.aux2, a.stats = ptr(aux1), ptr(aux2), ptr(_f32(stats, "stats"))
     ktot = sum(A.shape[1] for A, _ in pairs)
-    check(_timed("gemm", 2.0 * M * N * ktot, 0, lambda: lib().sr_gemm(C.byref(a), dtype_code(dt), stream())), "sr_gemm")
+    tag = "gemm_gate" if act in (ACT_SIGMOID, ACT_SIGMOID_MUL, ACT_TANH_BLEND, ACT_TANH) else "gemm"
+    check(_timed(tag, 2.0 * M * N * ktot, 0, lambda: lib().sr_gemm(C.byref(a), dtype_code(dt), stream())), "sr_gemm")
     return (out, out2) if two else out
 
 
@@ -110,7 +111,8 @@ def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_st
     # algorithmic bytes: input and weights read once, output written once, residual read once
     nbytes = es * (x.numel() + w.numel()) + (0 if stats_only else es * B * Ho * Wo * Cout) + (es * res.numel() if res is not None else 0)
     # a statistics-only launch re-does work the storing launch also does: its TIME counts, its FLOPs are not algorithmic
-    check(_timed("conv", 0.0 if stats_only else flops, float(nbytes), lambda: lib().sr_conv2d(C.byref(a), dtype_code(x.dtype), stream())), "sr_conv2d")
+    tag = "conv7x7" if stem_hw is not None else "conv%dx%d" % (KH, KH)
+    check(_timed(tag, 0.0 if stats_only else flops, float(nbytes), lambda: lib().sr_conv2d(C.byref(a), dtype_code(x.dtype), stream())), "sr_conv2d")
     if stats_only:
         return stats
     return (y, stats) if want_stats else y
@@ -151,8 +153,10 @@ def image_prep_u8(img_u8, dtype, out_hw=None, crop_yx=None, flip=None):
     return out
 
 
-def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps):
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, twin=None):
+    """`twin` = (running_mean2, running_var2, momentum2): a second BatchNorm's buffers updated from the same batch statistics."""
     require_gpu(stats, gamma, beta, running_mean, running_var)
+    rm2, rv2, m2 = twin if twin is not None else (None, None, 0.0)
     Cc = stats.shape[2]
     scale = torch.empty(Cc, device=stats.device, dtype=torch.float32)
     shift = torch.empty_like(scale)
@@ -163,7 +167,7 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
         _BN_SCRATCH[key] = scratch
     check(lib().sr_bn_finalize(stats.data_ptr(), stats.shape[0], Cc, int(count), gamma.data_ptr(), beta.data_ptr(),
                                ptr(running_mean), ptr(running_var), float(momentum), float(eps), scale.data_ptr(),
-                               shift.data_ptr(), scratch.data_ptr(), 1024, stream()), "sr_bn_finalize")
+                               shift.data_ptr(), scratch.data_ptr(), 1024, ptr(rm2), ptr(rv2), float(m2), stream()), "sr_bn_finalize")
     return scale, shift
 
 
@@ -186,7 +190,7 @@ def gemm_tn(A, B, out, accumulate=True):
     scratch = _TN_SCRATCH.get(key)
     if scratch is None or scratch.numel() < ns * N1 * N2:
         scratch = _TN_SCRATCH[key] = torch.empty(ns * N1 * N2, device=out.device, dtype=torch.float32)
-    check(_timed("gemm", 2.0 * M * N1 * N2, 0, lambda: lib().sr_gemm_tn(
+    check(_timed("gemm_tn", 2.0 * M * N1 * N2, 0, lambda: lib().sr_gemm_tn(
         A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), M, N1, N2, dtype_code(A.dtype), out.data_ptr(), int(accumulate),
         scratch.data_ptr(), scratch.numel(), stream())), "sr_gemm_tn")
     return out
@@ -224,9 +228,10 @@ def bn_apply_gram(x2d, scale, shift):
     return part
 
 
-def bn_finalize_gram(part, w, count, gamma, beta, running_mean, running_var, momentum, eps):
+def bn_finalize_gram(part, w, count, gamma, beta, running_mean, running_var, momentum, eps, twin=None):
     """Train-mode BN scale/shift (+ EMA) of the 1x1 conv with packed weights w [N, C] whose input has the partial Grams `part`."""
     require_gpu(part, w, gamma, beta, running_mean, running_var)
+    rm2, rv2, m2 = twin if twin is not None else (None, None, 0.0)
     N, Cc = w.shape
     E = Cc * Cc + Cc
     scale = torch.empty(N, device=part.device, dtype=torch.float32)
@@ -238,7 +243,8 @@ def bn_finalize_gram(part, w, count, gamma, beta, running_mean, running_var, mom
         _GRAM_SCRATCH[key] = scratch
     check(lib().sr_bn_finalize_gram(part.data_ptr(), part.shape[0], Cc, w.data_ptr(), w.stride(0), N, dtype_code(w.dtype), int(count),
                                     gamma.data_ptr(), beta.data_ptr(), ptr(running_mean), ptr(running_var), float(momentum),
-                                    float(eps), scale.data_ptr(), shift.data_ptr(), scratch.data_ptr(), scratch.numel(), stream()),
+                                    float(eps), scale.data_ptr(), shift.data_ptr(), scratch.data_ptr(), scratch.numel(), ptr(rm2), ptr(rv2),
+                                    float(m2), stream()),
           "sr_bn_finalize_gram")
     return scale, shift
 
@@ -247,8 +253,10 @@ def bn_apply(x, scale, shift, res=None, relu=True, out=None):
     require_gpu(x, scale, shift, res)
     out = torch.empty_like(x) if out is None else out
     Cc = x.shape[-1]
-    check(lib().sr_bn_apply(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), ptr(res), out.data_ptr(), x.numel() // Cc, Cc,
-                            int(relu), dtype_code(x.dtype), stream()), "sr_bn_apply")
+    nbytes = (2 + (res is not None)) * x.numel() * x.element_size()
+    check(_timed("bn_apply", 0, nbytes, lambda: lib().sr_bn_apply(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), ptr(res), out.data_ptr(),
+                                                                  x.numel() // Cc, Cc, int(relu), dtype_code(x.dtype), stream())),
+          "sr_bn_apply")
     return out
 
 
@@ -256,7 +264,8 @@ def maxpool3x3s2(x, scale=None, shift=None):
     require_gpu(x, scale, shift)
     B, H, W_, Cc = x.shape
     y = torch.empty((B, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, Cc), device=x.device, dtype=x.dtype)
-    check(lib().sr_maxpool3x3s2(x.data_ptr(), y.data_ptr(), B, H, W_, Cc, ptr(scale), ptr(shift), dtype_code(x.dtype), stream()),
+    check(_timed("maxpool", 0, (x.numel() + y.numel()) * x.element_size(),
+                 lambda: lib().sr_maxpool3x3s2(x.data_ptr(), y.data_ptr(), B, H, W_, Cc, ptr(scale), ptr(shift), dtype_code(x.dtype), stream())),
           "sr_maxpool3x3s2")
     return y
 
@@ -282,14 +291,42 @@ def node_init_fwd(feat, role_emb, verb_emb, verbs, role_table):
     return node
 
 
+_INV_INDEX = {}
+
+
+def _role_inverted_index(role_table, NR):
+    """CSR inverted index of the [V,R] role table: for every role id the slots v*R+r that hold it (static per encoder)."""
+    key = (role_table.data_ptr(), role_table._version, tuple(role_table.shape), NR)
+    hit = _INV_INDEX.get(key)
+    if hit is None:
+        flat = role_table.reshape(-1).long()
+        slots = torch.argsort(flat, stable=True)
+        ptrs = torch.zeros(NR + 2, dtype=torch.int64, device=role_table.device)
+        ptrs[1:] = torch.cumsum(torch.bincount(flat, minlength=NR + 1), 0)
+        if len(_INV_INDEX) > 16:
+            _INV_INDEX.clear()
+        hit = _INV_INDEX[key] = (ptrs[: NR + 1].to(torch.int32).contiguous(), slots.to(torch.int32).contiguous())
+    return hit
+
+
 def node_init_bwd(dnode, feat, role_emb, verb_emb, verbs, role_table, d_role_emb, d_verb_emb):
+    """Writes d_role_emb [NR+1,D] and d_verb_emb [V,D] in full (deterministic: see sr_node_init_bwd)."""
     require_gpu(dnode, feat, role_emb, verb_emb, verbs, role_table, d_role_emb, d_verb_emb)
     B, D = feat.shape
-    R = role_table.shape[1]
-    check(lib().sr_node_init_bwd(dnode.data_ptr(), feat.data_ptr(), role_emb.data_ptr(), verb_emb.data_ptr(), verbs.data_ptr(),
-                                 role_table.data_ptr(), _f32(d_role_emb, "d_role_emb").data_ptr(),
-                                 _f32(d_verb_emb, "d_verb_emb").data_ptr(), B, R, D, role_emb.shape[0] - 1,
-                                 dtype_code(feat.dtype), stream()), "sr_node_init_bwd")
+    V, R = role_table.shape
+    NR = role_emb.shape[0] - 1
+    if tuple(d_role_emb.shape) != (NR + 1, D) or tuple(d_verb_emb.shape) != (V, D) or verb_emb.shape[0] != V:
+        raise L.SrError("node_init_bwd: gradient / table shapes do not match")
+    order = torch.argsort(verbs, stable=True).to(torch.int32)
+    seg = torch.zeros(V + 1, dtype=torch.int32, device=verbs.device)
+    seg[1:] = torch.cumsum(torch.bincount(verbs, minlength=V), 0)
+    inv_ptr, inv_slot = _role_inverted_index(role_table, NR)
+    scratch = torch.empty((V * R, D), device=feat.device, dtype=torch.float32)
+    check(lib().sr_node_init_bwd(dnode.data_ptr(), feat.data_ptr(), role_emb.data_ptr(), verb_emb.data_ptr(), order.data_ptr(),
+                                 seg.data_ptr(), role_table.data_ptr(), inv_ptr.data_ptr(), inv_slot.data_ptr(),
+                                 scratch.data_ptr(), _f32(d_role_emb, "d_role_emb").data_ptr(),
+                                 _f32(d_verb_emb, "d_verb_emb").data_ptr(), B, R, D, V, NR, dtype_code(feat.dtype), stream()),
+          "sr_node_init_bwd")
 
 
 def aggregate(h, adj_table, verbs, R, transpose=False, add=None, out=None):
@@ -308,16 +345,18 @@ def aggregate(h, adj_table, verbs, R, transpose=False, add=None, out=None):
 def gru_bwd1(dh, z, c, h):
     require_gpu(dh, z, c, h)
     dc, dz, dacc = torch.empty_like(dh), torch.empty_like(dh), torch.empty_like(dh)
-    check(lib().sr_gru_bwd1(dh.data_ptr(), z.data_ptr(), c.data_ptr(), h.data_ptr(), dc.data_ptr(), dz.data_ptr(),
-                            dacc.data_ptr(), dh.numel(), dtype_code(dh.dtype), stream()), "sr_gru_bwd1")
+    check(_timed("gru_bwd", 0, 7 * dh.numel() * dh.element_size(),       # reads dh, z, c, h; writes dc, dz, dacc
+                 lambda: lib().sr_gru_bwd1(dh.data_ptr(), z.data_ptr(), c.data_ptr(), h.data_ptr(), dc.data_ptr(), dz.data_ptr(),
+                                           dacc.data_ptr(), dh.numel(), dtype_code(dh.dtype), stream())), "sr_gru_bwd1")
     return dc, dz, dacc
 
 
 def gru_bwd2(drh, r, h, dh_acc):
     require_gpu(drh, r, h, dh_acc)
     dr = torch.empty_like(drh)
-    check(lib().sr_gru_bwd2(drh.data_ptr(), r.data_ptr(), h.data_ptr(), dr.data_ptr(), dh_acc.data_ptr(), drh.numel(),
-                            dtype_code(drh.dtype), stream()), "sr_gru_bwd2")
+    check(_timed("gru_bwd", 0, 6 * drh.numel() * drh.element_size(),     # reads drh, r, h, dacc; writes dr, dacc
+                 lambda: lib().sr_gru_bwd2(drh.data_ptr(), r.data_ptr(), h.data_ptr(), dr.data_ptr(), dh_acc.data_ptr(), drh.numel(),
+                                           dtype_code(drh.dtype), stream())), "sr_gru_bwd2")
     return dr
 
 

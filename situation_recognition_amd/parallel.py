@@ -1,11 +1,20 @@
 """Data parallelism for the training step: one process per GPU, weights resident on every rank, each
-rank reads its own shard of the batch, ONE all-reduce of the flat trainable-gradient buffer per step
-(RCCL over xGMI through torch.distributed's "nccl" backend; "gloo" on CPU for tests).
+rank reads its own shard of the batch, and the trainable gradients (35.9 M fp32 = 143.7 MB) are summed over the ranks
+with RCCL over xGMI (torch.distributed's "nccl" backend; "gloo" on CPU for tests) -- in buckets, one per large
+parameter tensor (each 2048 x 2048 GGNN matrix is its own 16.8 MB bucket), launched from autograd hooks the moment a
+bucket's gradients exist, on the collective's own stream, so the exchange runs behind the rest of the backward.
 
 Replaces the reference's `torch.nn.DataParallel` (sr.py:467-470), which every step scatters the input
 from GPU 0, re-broadcasts all weights, gathers the logits and reduces the gradients onto GPU 0
 (SURVEY 2a).  The frozen backbones (2 x 58 M parameters) are never communicated; BatchNorm statistics
 stay per rank, exactly as under DataParallel (no SyncBN).
+
+Exact loss semantics.  The reference computes its cross-entropy means on GPU 0 over the GATHERED global batch
+(sr.py:67-76 after DataParallel's gather): verb_loss divides by the global batch size, and each of the three noun terms
+(model.py:196-199, `ignore_index`) by the GLOBAL number of non-ignored targets.  A mean of per-rank means is a different
+number whenever ranks hold different counts, so here every rank divides its loss SUMS by the global denominators
+(`loss_denominators`: one all-reduce of four integers before backward) and the gradient exchange is a plain SUM --
+which is then exactly the gradient of the reference's global-batch loss.
 """
 import os
 
@@ -30,45 +39,124 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-class GradBucket:
-    """Flat fp32 bucket over the trainable parameters.  `reduce()` copies the gradients in, runs one
-    all-reduce(sum) and scatters `sum / world` back, so `clip_grad_norm_` afterwards sees the gradient of the
-    mean loss over the GLOBAL batch (the reference clips after DataParallel's reduction, sr.py:79-81)."""
+def _world(group=None):
+    return dist.get_world_size(group) if dist.is_initialized() else 1
 
-    def __init__(self, params, group=None):
+
+def loss_denominators(gt_verb, gt_nouns, ignore_index, group=None):
+    """Global denominators of the reference's loss means: (B_global, n_global[3]) as fp32 tensors on the labels' device,
+    where n[i] = number of targets of annotator i that are not `ignore_index`.  One all-reduce of 4 integers."""
+    counts = torch.cat([torch.tensor([gt_verb.shape[0]], device=gt_nouns.device, dtype=torch.int64),
+                        (gt_nouns != ignore_index).sum(dim=(0, 2)).to(torch.int64)])
+    if _world(group) > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    counts = counts.to(torch.float32)
+    return counts[0], counts[1:]
+
+
+def global_batch_loss(model, pred_verb, pred_nouns, gt_verb, gt_nouns, group=None):
+    """This rank's share of the reference's training loss `verb_loss + nouns_loss` (sr.py:67-76) over the GLOBAL batch:
+    summing the returned values over the ranks gives the loss a single replica would compute on the gathered batch, and
+    summing the gradients gives its gradient.  Returns (loss, verb_share, nouns_share, (B_global, n_global[3]))."""
+    L = model.encoder.get_num_labels()
+    b_glob, n_glob = loss_denominators(gt_verb, gt_nouns, L, group)
+    vl = model.verb_loss(pred_verb, gt_verb, denom=b_glob)
+    nl = model.nouns_loss(pred_nouns, gt_nouns, denoms=n_glob)
+    return vl + nl, vl, nl, (b_glob, n_glob)
+
+
+class GradBucket:
+    """Flat fp32 buffer over the trainable parameters whose slices ARE the parameters' `.grad` tensors, cut into buckets.
+
+        bucket.zero()              instead of optimizer.zero_grad()   (keeps .grad pointing into the buffer)
+        loss.backward()            autograd accumulates into the views; when the last gradient of a bucket has been
+                                   written, its hook launches an asynchronous all-reduce(SUM) of that slice
+        bucket.finish()            launches what is left (parameters that received no gradient stay zero) and waits
+
+    Afterwards every rank holds the SUM of the ranks' gradients (`average=True`: the mean, for losses that are per-rank
+    means).  With the loss of `global_batch_loss` the sum is the global-batch gradient, so `clip_grad_norm_` after
+    `finish()` sees what the reference's single replica sees (sr.py:79-81).
+    """
+
+    def __init__(self, params, group=None, average=False, min_bucket_bytes=4 << 20):
         self.params = [p for p in params if p.requires_grad]
-        self.group = group
+        self.group, self.average = group, average
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.views, o = [], 0
+        self.views, self.spans, o = [], [], 0
         for p in self.params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            self.spans.append((o, o + p.numel()))
             o += p.numel()
+        # buckets in REVERSE parameter order (the order gradients become available in); a tensor of >= min_bucket_bytes
+        # closes the bucket it falls in, smaller ones (biases, small embeddings) ride along with their neighbours
+        self.buckets, cur = [], []
+        for i in reversed(range(len(self.params))):
+            cur.append(i)
+            if sum(self.params[j].numel() for j in cur) * 4 >= min_bucket_bytes:
+                self.buckets.append(cur)
+                cur = []
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {}
+        for b, idxs in enumerate(self.buckets):
+            for i in idxs:
+                self._bucket_of[i] = b
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._pending = [len(b) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        for p in self.params:
+            p.grad = self.views[self._index[id(p)]]
+            p.register_post_accumulate_grad_hook(self._on_grad)
 
     @property
     def nbytes(self):
         return self.flat.numel() * 4
 
-    def reduce(self, weight=1.0):
-        """weight: this rank's share of the global mean (default 1 -> plain average over ranks)."""
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        with torch.no_grad():
-            for v, p in zip(self.views, self.params):
-                if p.grad is None:
-                    v.zero_()
-                else:
-                    v.copy_(p.grad)
-            if world > 1:
-                if weight != 1.0:
-                    self.flat.mul_(weight)
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-                self.flat.div_(world)
-                for v, p in zip(self.views, self.params):
-                    if p.grad is None:
-                        p.grad = v.clone()
-                    else:
-                        p.grad.copy_(v)
+    def zero(self):
+        self.flat.zero_()
+        for i, p in enumerate(self.params):
+            if p.grad is None or p.grad.data_ptr() != self.views[i].data_ptr():
+                p.grad = self.views[i]
+        self._pending = [len(b) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+
+    def _span(self, b):
+        idxs = self.buckets[b]
+        return min(self.spans[i][0] for i in idxs), max(self.spans[i][1] for i in idxs)
+
+    def _launch(self, b):
+        self._launched[b] = True
+        if _world(self.group) > 1:
+            lo, hi = self._span(b)
+            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _on_grad(self, p):
+        i = self._index[id(p)]
+        if p.grad.data_ptr() != self.views[i].data_ptr():      # .grad was reset to None before backward: adopt the new tensor
+            self.views[i].copy_(p.grad)
+            p.grad = self.views[i]
+        b = self._bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and not self._launched[b]:
+            self._launch(b)
+
+    def finish(self):
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.average and _world(self.group) > 1:
+            self.flat.div_(_world(self.group))
+
+    def reduce(self):
+        """One-call form for code that does not use the hooks' overlap: everything not yet launched goes now."""
+        self.finish()
 
 
 def shard_range(total, rank, world):

@@ -37,7 +37,24 @@ def _print_scores(prefix, losses, top1_a, top5_a, avg):
                                              utils.format_dict(gt, '{:.2f}', ''), avg))
 
 
+class _EvalShard(torch.utils.data.Sampler):
+    """Evaluation shard of a rank: samples rank, rank+world, ... -- no padding, no duplicates (DistributedSampler pads by
+    repeating samples, which would count them twice in the metric)."""
+
+    def __init__(self, n, rank, world):
+        self.ids = range(rank, n, world)
+
+    def __iter__(self):
+        return iter(self.ids)
+
+    def __len__(self):
+        return len(self.ids)
+
+
 def eval(model, loader, encoder, logging=False):                         # noqa: A001  (reference name, sr.py:165)
+    """reference sr.py:165-232.  With several ranks each one scores its shard of the set and the score-card sums, sample
+    counts and loss sums are all-reduced, so every rank returns (and rank 0 prints / checkpoints) the metric of the WHOLE
+    set, as the reference's single process does."""
     model.eval()
     dev = next(model.parameters()).device
     top1, top5 = imsitu_scorer(encoder, 1, 3), imsitu_scorer(encoder, 5, 3)
@@ -51,6 +68,12 @@ def eval(model, loader, encoder, logging=False):                         # noqa:
             for i, l in enumerate((model.verb_loss(pv, verb), model.nouns_loss(pn, nouns), model.nouns_loss(pg, nouns))):
                 sums[i] += l.item()
             n += 1
+    if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        t = torch.tensor(sums + [float(n)], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(t)
+        sums, n = t[:3].tolist(), int(t[3])
+        top1.all_reduce_()
+        top5.all_reduce_()
     losses = [s / max(n, 1) for s in sums]
     val_losses = {'verb_loss': losses[0], 'nouns_loss': losses[1], 'gt_loss': losses[2]}
     avg = 0
@@ -78,18 +101,36 @@ def train(model, train_loader, dev_loader, optimizer, max_epoch, encoder, model_
     bucket = parallel.GradBucket(params) if torch.distributed.is_initialized() else None
     model.train()
     for e in range(epoch, max_epoch):
+        for ld in (train_loader, getattr(train_loader, "sampler", None)):   # a new permutation every epoch (DistributedSampler
+            if hasattr(ld, "set_epoch"):                                     # replays epoch 0's until told otherwise)
+                ld.set_epoch(e)
         if rank == 0:
             print('Epoch-{}, lr: {:.4f}'.format(e, optimizer.param_groups[0]['lr']))
         top1, top5 = imsitu_scorer(encoder, 1, 3), imsitu_scorer(encoder, 5, 3)
         acc = [0.0, 0.0, 0.0]
         for _, img, verb, nouns in train_loader:
             img, verb, nouns = img.to(dev), verb.to(dev), nouns.to(dev)
-            optimizer.zero_grad()
+            if bucket is None:
+                optimizer.zero_grad()
+            else:
+                bucket.zero()                                            # .grad tensors are views of the flat bucket
             pv, pn, pg = model(img, verb)
-            vl, nl, gl = model.verb_loss(pv, verb), model.nouns_loss(pn, nouns), model.nouns_loss(pg, nouns)
-            (vl + nl).backward()                                         # sr.py:76-79 (gt loss is logged only)
-            if bucket is not None:
-                bucket.reduce()
+            if bucket is None:
+                vl, nl = model.verb_loss(pv, verb), model.nouns_loss(pn, nouns)
+                gl = model.nouns_loss(pg, nouns)
+                (vl + nl).backward()                                     # sr.py:76-79 (gt loss is logged only)
+            else:
+                # loss means over the GLOBAL batch (the reference computes them after DataParallel's gather, sr.py:67-76):
+                # per-rank sums over global denominators, then a plain SUM of the gradients, launched bucket by bucket
+                # from autograd hooks while the backward is still running
+                loss, vl, nl, (_, n_glob) = parallel.global_batch_loss(model, pv, pn, verb, nouns)
+                with torch.no_grad():
+                    gl = model.nouns_loss(pg, nouns, denoms=n_glob)
+                loss.backward()
+                bucket.finish()
+                logged = torch.stack([vl.detach(), nl.detach(), gl.detach()])
+                torch.distributed.all_reduce(logged)                     # shares -> the global-batch values, for the log line
+                vl, nl, gl = logged[0], logged[1], logged[2]
             torch.nn.utils.clip_grad_norm_(params, 1)                    # sr.py:81
             optimizer.step()
             top1.add_point_both(pv, verb, pn, nouns, pg)
@@ -97,6 +138,9 @@ def train(model, train_loader, dev_loader, optimizer, max_epoch, encoder, model_
             for i, l in enumerate((vl, nl, gl)):
                 acc[i] += l.item()
         nb = max(len(train_loader), 1)
+        if bucket is not None:                                           # the epoch's training metric over every rank's samples
+            top1.all_reduce_()
+            top5.all_reduce_()
         t1, t5 = top1.get_average_results_both(), top5.get_average_results_both()
         avg = _mean8(t1, t5)
         hist['avg_scores'].append(avg)
@@ -199,6 +243,10 @@ def main(argv=None):
                 n = write_shards(args.imgset_dir, list(json.load(open(path))), _shard_dir(args, f), quiet=False)
                 print('{}: {} shards under {}'.format(f, n, _shard_dir(args, f)))
         return
+    if args.subset:
+        # reference sr.py:284-380,529 (`analize_subset`): an IPython notebook pretty-printer over random dev images -- outside the
+        # hot path.  Refuse instead of falling through to training (which would overwrite the checkpoint).
+        raise SystemExit("--subset (analize_subset) is not implemented in this build; use --test_img for single images")
     rank, world, local = parallel.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("situation_recognition_amd.sr needs an MI355X (no CPU fallback)")
@@ -261,8 +309,9 @@ def _loader(args, ann, encoder, transform, shuffle, rank, world, fname=None):
                            train=shuffle, rank=rank, world=world)
     ds = imsitu_loader.imsitu_loader(args.imgset_dir, ann, encoder, transform)
     sampler = None
-    if world > 1:
-        sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle)
+    if world > 1:      # training: equal (padded) shards -- every batch ends in an all-reduce; evaluation: every sample once
+        sampler = (torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True) if shuffle
+                   else _EvalShard(len(ds), rank, world))
     return torch.utils.data.DataLoader(ds, pin_memory=True, batch_size=max(1, args.batch_size // world),
                                        shuffle=(shuffle and sampler is None), sampler=sampler, num_workers=args.num_workers)
 

@@ -3,8 +3,9 @@
 config 2  ResNet-50 + 6-role GGNN T=4, batch 256, fp32: eval-mode logits of the first 8 images against the CPU oracle
           (<= 1e-3, the north_star tolerance), and -- size-independent property -- every image's logits in the batch-256
           run equal its logits when run in a batch of 8 (eval-mode BatchNorm makes images independent).
-config 3  ResNet-152 + 6-role GGNN T=5, bf16, imSitu-sized vocabulary: same slicing property at a large batch, plus
-          train-mode invariants (finite losses, running statistics move, gradients reach every trainable parameter).
+config 3  ResNet-152 + 6-role GGNN T=5, bf16, imSitu-sized vocabulary, batch 6144 (the benchmark's per-GPU size): same slicing
+          property, eight images against the fp32 oracle, plus train-mode invariants (finite losses, running statistics move,
+          gradients reach every trainable parameter).
 """
 import pytest
 import torch
@@ -49,32 +50,59 @@ def test_config2_resnet50_fp32_batch256_vs_oracle():
         want = ora(img[:8], verb[:8])
     for f, s, w in zip(full, small, want):
         scale = max(1.0, float(w.abs().max()))
-        assert float((s.cpu() - w).abs().max()) < 1e-3 * scale, (float((s.cpu() - w).abs().max()), scale)   # north_star tolerance
+        err = float((s.cpu() - w).abs().max())
+        print("config2 fp32 vs oracle: max abs err %.2e (logit range %.2f)" % (err, float(w.abs().max())))
+        assert err < 1e-3, err                                              # north_star tolerance: ABSOLUTE 1e-3 on the logits
         assert float((f[:8] - s).abs().max()) < 2e-5 * scale                # batch independence in eval mode
     assert torch.equal(full[0].argmax(1)[:8].cpu(), want[0].argmax(1))
 
 
-def test_config3_resnet152_bf16_slicing_and_train_invariants():
+def _device_images(B, seed):
+    gd = torch.Generator(device="cuda").manual_seed(seed)
+    img = torch.empty((B, 3, 224, 224), device="cuda")
+    for i in range(0, B, 512):
+        img[i:i + 512] = torch.randn((min(512, B - i), 3, 224, 224), device="cuda", generator=gd).clamp_(-2.2, 2.7)
+    return img
+
+
+def test_config3_resnet152_bf16_batch6144_slicing_oracle_and_train_invariants():
+    """BASELINE config 3 at its FULL size (per-GPU batch 6144: the largest activation is 9.9 GB, row counts up to 77 M --
+    the >2^31-byte regime): eval-mode logits of slices of the batch equal the same images run alone (eval BatchNorm
+    makes images independent; same K order per output element whatever the batch), eight of them are compared with the fp32
+    CPU oracle, and one train-mode step keeps the invariants of reference model.py:172-180 / sr.py:63-83."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    net, _ = _nets(152, 5, torch.bfloat16)
+    net, ora = _nets(152, 5, torch.bfloat16)
     g = torch.Generator().manual_seed(6)
-    B = 768
-    img = torch.randn(B, 3, 224, 224, generator=g).clamp_(-2.2, 2.7).cuda()
+    B = 6144
+    img = _device_images(B, 6)
     verb = torch.randint(0, 504, (B,), generator=g).cuda()
-    net.eval()
+    net.eval(); ora.eval()
     with torch.no_grad():
         full = net(img, verb)
-        part = net(img[320:352].contiguous(), verb[320:352].contiguous())
-    for f, p in zip(full, part):
+        parts = {lo: net(img[lo:lo + 32].contiguous(), verb[lo:lo + 32].contiguous()) for lo in (0, 3040, B - 32)}
+        want = ora(img[3040:3048].float().cpu(), verb[3040:3048].cpu())
+    for f in full:
         assert torch.isfinite(f).all()
-        # same K order per output element whatever the batch -> identical up to the tile a row lands in (exact here)
-        assert float((f[320:352].float() - p.float()).abs().max()) <= 1e-2 * max(1.0, float(p.float().abs().max()))
-    # train mode: one step's invariants
+    for lo, part in parts.items():
+        for f, p in zip(full, part):
+            assert float((f[lo:lo + 32].float() - p.float()).abs().max()) <= 1e-2 * max(1.0, float(p.float().abs().max())), lo
+    # bf16 storage through 152 layers against the fp32 oracle: no 1e-3 claim here (that is config 2, fp32 storage); the bound
+    # is what bf16 rounding of every activation gives on this net (measured 2-3 % of the logit range; asserted at 8 %)
+    for f, w, name in zip(full, want, ("verb", "nouns", "gt_nouns")):
+        err = float((f[3040:3048].float().cpu() - w).abs().max())
+        rng = float(w.abs().max())
+        print("config3 bf16 vs fp32 oracle, %s logits: max err %.4f of range %.3f" % (name, err, rng))
+        assert err <= 0.08 * max(1.0, rng), (name, err, rng)
+    assert torch.equal(full[0][3040:3048].float().argmax(1).cpu(), want[0].argmax(1))
+    del full, parts
+    # train mode: one step's invariants at the full batch
     net.train()
     nouns = torch.randint(0, 2001, (B, 3, 6), generator=g).cuda()
     rv0 = net.convnet_verbs.model.layer3[5].bn2.running_var.clone()
     pv, pn, pg = net(img, verb)
+    for t in (pv, pn, pg):
+        assert torch.isfinite(t).all()
     loss = net.verb_loss(pv, verb) + net.nouns_loss(pn, nouns)
     assert torch.isfinite(loss) and 5.0 < float(net.verb_loss(pv, verb)) < 9.0          # ~ ln(504) at init
     loss.backward()
@@ -114,8 +142,8 @@ def test_gram_statistics_route_matches_statistics_only_launch_in_the_backbone():
         last_x["x"] = x2d
         return part
 
-    def fin(part, w, count, gamma, beta, rm, rv, momentum, eps):
-        scale, shift = fin0(part, w, count, gamma, beta, rm, rv, momentum, eps)
+    def fin(part, w, count, gamma, beta, rm, rv, momentum, eps, twin=None):
+        scale, shift = fin0(part, w, count, gamma, beta, rm, rv, momentum, eps, twin=twin)
         x2d = last_x["x"]
         st = ops.conv2d(x2d.view(1, x2d.shape[0], 1, x2d.shape[1]), w.reshape(w.shape[0], -1), w.shape[0], 1, 1, 0, stats_only=True)
         s2, h2 = ops.bn_finalize(st, count, gamma, beta, None, None, momentum, eps)

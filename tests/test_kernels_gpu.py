@@ -263,6 +263,11 @@ def test_node_init_and_aggregate(ops, dtype):
     re.grad[NR] = 0                                            # padding_idx semantics
     close(dre, re.grad, torch.float32, k=20)
     close(dve, ve.grad, torch.float32, k=20)
+    assert float(dre[NR].abs().max()) == 0.0
+    # fixed summation order: a second launch (into garbage-initialised buffers: both are written in full) is bit-identical
+    dre2, dve2 = torch.full((NR + 1, D), 7.0).cuda(), torch.full((V, D), -3.0).cuda()
+    ops.node_init_bwd(dn.cuda(), feat.cuda(), role_emb.cuda(), verb_emb.cuda(), verbs.cuda(), table.cuda(), dre2, dve2)
+    assert torch.equal(dre, dre2) and torch.equal(dve, dve2)
     h = rnd(B * R, D, dtype=dtype, seed=6)
     A = adj[verbs]
     close(ops.aggregate(h.cuda(), adj.cuda(), verbs.cuda(), R), torch.bmm(A, h.float().view(B, R, D)).view(B * R, D), dtype)

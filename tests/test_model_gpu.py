@@ -256,5 +256,63 @@ def test_two_stream_backbones_give_identical_results(sra):
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
-        if p.requires_grad:      # (embedding gradients are float atomics: equal up to summation order)
+        if p.requires_grad:
             assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-6 * float(q.grad.abs().max())), k
+            if "emb" in k:       # sr_node_init_bwd sums in a fixed order (no atomics): bit-reproducible
+                assert torch.equal(p.grad, q.grad), k
+
+
+def test_identical_backbones_share_one_train_pass(sra):
+    """The reference loads the SAME pretrained weights into both backbones and freezes them (model.py:16-18,100-101); train-mode
+    BatchNorm ignores running statistics, so one pass serves both.  Shared pass vs separate passes: bit-identical logits,
+    gradients and BatchNorm buffers (verbs: one update; nouns: two, model.py:176-178); and both against the oracle, whose
+    three passes are executed literally."""
+    import copy
+    g3, g5 = load("g3_fcggnn_bottleneck.npz"), load("g5_train_step.npz")
+    net, _ = hip_fcggnn(sra, g3)
+    ora, _, _ = oracle_fcggnn(g3)
+    net.convnet_nouns.load_state_dict(net.convnet_verbs.state_dict())
+    ora.convnet_nouns.load_state_dict(ora.convnet_verbs.state_dict())
+    with torch.no_grad():                                  # different running statistics must not matter (train mode) nor be mixed up
+        for bn in (m_ for m_ in net.convnet_nouns.modules() if isinstance(m_, torch.nn.BatchNorm2d)):
+            bn.running_mean.add_(0.25); bn.running_var.mul_(1.5)
+        for bn in (m_ for m_ in ora.convnet_nouns.modules() if isinstance(m_, torch.nn.BatchNorm2d)):
+            bn.running_mean.add_(0.25); bn.running_var.mul_(1.5)
+    assert net.convnet_verbs.weights_equal(net.convnet_nouns)
+    shared, separate = net, copy.deepcopy(net)
+    separate.share_identical_backbones = False
+    img, verb, nouns = torch.from_numpy(g3["img"]), torch.from_numpy(g3["gt_verb"]), torch.from_numpy(g5["gt_nouns"])
+    outs = []
+    for m_ in (shared, separate, ora):
+        m_.train()
+        m_.verb_classifier[0].p = 0.0
+        m_.nouns_classifier[0].p = 0.0
+        dev = "cpu" if m_ is ora else "cuda"
+        pv, pn, pg = m_(img.to(dev), verb.to(dev))
+        (m_.verb_loss(pv, verb.to(dev)) + m_.nouns_loss(pn, nouns.to(dev))).backward()
+        outs.append((pv, pn, pg))
+    calls = []
+    orig = shared.convnet_nouns._forward_impl
+    shared.convnet_nouns._forward_impl = lambda *a, **k: calls.append(1) or orig(*a, **k)
+    shared(img.cuda(), verb.cuda())                        # (second step: the noun backbone itself never runs)
+    assert not calls
+    for x, y, z in zip(*outs):
+        assert torch.equal(x, y)
+        assert float((x.detach().cpu() - z.detach()).abs().max()) < TOL
+    sa, sb, so = shared.state_dict(), separate.state_dict(), ora.state_dict()
+    for (k, p), (_, q) in zip(shared.named_parameters(), separate.named_parameters()):
+        if p.requires_grad:
+            assert torch.equal(p.grad, q.grad), k
+    with torch.no_grad():
+        separate(img.cuda(), verb.cuda())
+        ora(img, verb)
+    sa, sb, so = shared.state_dict(), separate.state_dict(), ora.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+        if "running" in k or "num_batches" in k:
+            assert float((sa[k].float().cpu() - so[k].float()).abs().max()) <= 1e-3 * max(1.0, float(so[k].float().abs().max())), k
+    assert int(sa["convnet_nouns.model.bn1.num_batches_tracked"]) == 4 and int(sa["convnet_verbs.model.bn1.num_batches_tracked"]) == 2
+    # diverging weights switch the sharing off again
+    with torch.no_grad():
+        shared.convnet_nouns.model.layer1[0].conv1.weight.mul_(1.01)
+    assert not shared.convnet_verbs.weights_equal(shared.convnet_nouns)

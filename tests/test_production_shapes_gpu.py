@@ -1,0 +1,179 @@
+"""bf16 parity of the kernels that carry the benchmark, at shapes that select them.
+
+Round 1's kernel tests all landed on the narrow tiles or the fallback kernels (`sr_gemm_tile_cfg` = 1 / 2 / 0); the
+256x256 half-step ping-pong kernels -- `conv_igemm_v3_kernel<bf16,bf16,4,0|1>` (layer3's convolutions: the row-layout
+residual, the staged bf16 store inside a ring slot, running BatchNorm sums over several tiles per workgroup) and
+`gemm_nt_v3_kernel<bf16,bf16,4,EPI>` (GGNN gates) -- were only compared with themselves.  Here every case asserts
+`sr_gemm_tile_cfg(...) == 4`, runs >= 3 tiles per workgroup (tile-to-tile ring hand-over) and is compared with a plain
+fp32 reference computed from the bf16-rounded operands (torch fp32 matmul on the device over an explicit im2col; a CPU
+`F.conv2d` / `F.batch_norm` cross-check of the first images guards the reference itself).
+Arithmetic of reference model.py:35 (torchvision Bottleneck conv/BN/ReLU/residual) and model.py:80-84 (GRU gates).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from situation_recognition_amd import ops as o
+    o.lib()
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=BF):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device="cuda") * scale).to(dtype)
+
+
+def tol(ref, k=1.0):                                  # bf16 output rounding (2^-9 relative) with margin, as tests/test_kernels_gpu.py
+    return 1.2e-2 * (float(ref.abs().max()) + 1e-6) * k
+
+
+def close(got, ref, k=1.0):
+    err = float((got.float() - ref).abs().max())
+    assert err <= tol(ref, k), "max err %g > tol %g" % (err, tol(ref, k))
+
+
+def cfg(ops, M, N, linear=True):
+    return ops.lib().sr_gemm_tile_cfg(int(M), int(N), int(linear), 1)
+
+
+def conv_ref(x_nhwc, w, k, pad):
+    """fp32 convolution of bf16-rounded operands as an explicit im2col + fp32 matmul on the device.
+    x_nhwc [B,H,W,C] bf16, w [Cout,Cin,k,k] bf16 -> [B*H*W, Cout] fp32 (stride 1)."""
+    B, H, W_, Cc = x_nhwc.shape
+    xf = x_nhwc.float()
+    if k == 1:
+        return xf.view(-1, Cc) @ w.float().view(w.shape[0], Cc).t()
+    xp = F.pad(xf, (0, 0, pad, pad, pad, pad))
+    out = torch.zeros(B * H * W_, w.shape[0], device=xf.device)
+    for r in range(k):
+        for q in range(k):
+            out += xp[:, r:r + H, q:q + W_, :].reshape(-1, Cc) @ w[:, :, r, q].float().t()
+    return out
+
+
+def pack_w(w):                                        # [Cout,Cin,KH,KW] -> [Cout, KH*KW*Cin]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+B14 = 1024                                            # 1024 x 14 x 14 = 200 704 output rows = 784 row tiles of 256
+
+
+def test_conv3x3_256_256_statistics_kernel(ops):
+    """layer3's 3x3 (35 launches per pass, 14 % of the step): `<bf16,bf16,4,1>` -- raw bf16 output + running BatchNorm
+    partial sums over 3-4 tiles per workgroup; padding taps through out-of-range buffer loads."""
+    Cc = 256
+    M = B14 * 196
+    assert cfg(ops, M, Cc) == 4
+    x = rnd(B14, 14, 14, Cc, seed=1)
+    w = rnd(Cc, Cc, 3, 3, seed=2, scale=(Cc * 9) ** -0.5)
+    y, stats = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, want_stats=True)
+    ref = conv_ref(x, w, 3, 1)
+    close(y.view(M, Cc), ref)
+    cpu = F.conv2d(x[:2].float().cpu().permute(0, 3, 1, 2), w.float().cpu(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cc)
+    assert float((ref[: 2 * 196].cpu() - cpu).abs().max()) < 1e-4 * float(cpu.abs().max())
+    s1, s2 = stats[:, 0].double().sum(0), stats[:, 1].double().sum(0)
+    r1, r2 = ref.double().sum(0), (ref.double() ** 2).sum(0)
+    assert float((s1 - r1).abs().max()) < 1e-4 * float(ref.abs().sum(0).max())
+    assert float(((s2 - r2).abs() / r2).max()) < 1e-4
+    # and through the BatchNorm it feeds: finalize + apply against F.batch_norm(train) + ReLU of the fp32 reference
+    gamma, beta = 0.5 + torch.rand(Cc, device="cuda"), 0.2 * torch.randn(Cc, device="cuda")
+    rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    scale, shift = ops.bn_finalize(stats, M, gamma, beta, rm, rv, 0.1, 1e-5)
+    want = F.relu(F.batch_norm(ref.t().reshape(1, Cc, M), None, None, gamma, beta, training=True, eps=1e-5)).view(Cc, M).t()
+    out = ops.bn_apply(y, scale, shift, relu=True)
+    close(out.view(M, Cc), want, k=2.0)
+
+
+def test_conv1x1_256_1024_scale_residual_relu(ops):
+    """layer3's expansion conv (36 launches per pass, 18 % of the step): `<bf16,bf16,4,0>` with the per-channel multiplier,
+    bias, ROW-LAYOUT residual prefetched three strips ahead, ReLU and the staged store."""
+    Cin, Cout = 256, 1024
+    M = B14 * 196
+    assert cfg(ops, M, Cout) == 4
+    x = F.relu(rnd(B14, 14, 14, Cin, seed=3)).to(BF)
+    w = rnd(Cout, Cin, 1, 1, seed=4, scale=Cin ** -0.5)
+    idn = rnd(B14, 14, 14, Cout, seed=5)
+    esc, bias = 0.5 + torch.rand(Cout, device="cuda"), 0.3 * torch.randn(Cout, device="cuda")
+    y = ops.conv2d(x, pack_w(w), Cout, 1, 1, 0, bias=bias, escale=esc, res=idn, relu=True)
+    ref = F.relu(conv_ref(x, w, 1, 0) * esc + bias + idn.float().view(M, Cout))
+    close(y.view(M, Cout), ref)
+    # the statistics route in front of it (Gram matrix of the input) against F.batch_norm(train) of the fp32 conv
+    gamma, beta = 0.5 + torch.rand(Cout, device="cuda"), 0.2 * torch.randn(Cout, device="cuda")
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    part = ops.gram(x.view(M, Cin))
+    scale, shift = ops.bn_finalize_gram(part, pack_w(w), M, gamma, beta, rm, rv, 0.1, 1e-5)
+    y2 = ops.conv2d(x, pack_w(w), Cout, 1, 1, 0, bias=shift, escale=scale, res=idn, relu=True)
+    conv = conv_ref(x, w, 1, 0)
+    want = F.relu(F.batch_norm(conv.t().reshape(1, Cout, M), None, None, gamma, beta, training=True, eps=1e-5).view(Cout, M).t()
+                  + idn.float().view(M, Cout))
+    close(y2.view(M, Cout), want, k=2.0)
+    mean, var = conv.double().mean(0), conv.double().var(0, unbiased=True)
+    assert float((rm.double() - 0.1 * mean).abs().max()) < 2e-3 and float((rv.double() - (0.9 + 0.1 * var)).abs().max()) < 2e-3
+
+
+def test_conv1x1_1024_256_statistics_kernel(ops):
+    """layer3's reduce conv (35 launches per pass): K = 1024 -> 32 K-steps per tile, statistics kernel."""
+    Cin, Cout = 1024, 256
+    M = B14 * 196
+    assert cfg(ops, M, Cout) == 4
+    x = F.relu(rnd(B14, 14, 14, Cin, seed=6)).to(BF)
+    w = rnd(Cout, Cin, 1, 1, seed=7, scale=Cin ** -0.5)
+    y, stats = ops.conv2d(x, pack_w(w), Cout, 1, 1, 0, want_stats=True)
+    ref = conv_ref(x, w, 1, 0)
+    close(y.view(M, Cout), ref)
+    s1, s2 = stats[:, 0].double().sum(0), stats[:, 1].double().sum(0)
+    assert float((s1 - ref.double().sum(0)).abs().max()) < 1e-4 * float(ref.abs().sum(0).max())
+    assert float(((s2 - (ref.double() ** 2).sum(0)).abs() / (ref.double() ** 2).sum(0)).max()) < 1e-4
+    # ragged M (a last row tile that is partly out of range) on the same kernel
+    Br = 1021
+    y2 = ops.conv2d(x[:Br].contiguous(), pack_w(w), Cout, 1, 1, 0)
+    close(y2.view(-1, Cout), ref[: Br * 196])
+
+
+@pytest.mark.parametrize("M", [6144, 36864 + 100])
+def test_gemm_2048_all_epilogues_on_the_ping_pong_kernel(ops, M):
+    """GGNN shapes (reference model.py:64,75,80-84): N = K = 2048, M = the verb path's 6144 rows (96 tiles) and the noun
+    path's 36 864 (+100: a ragged last tile), 1-3 operand pairs, all five epilogues of `gemm_nt_v3_kernel<bf16,bf16,4,*>`."""
+    D = 2048
+    for lin in (True, False):
+        assert cfg(ops, M, D, lin) == 4
+    n, h, rh = rnd(M, D, seed=1), rnd(M, D, seed=2), rnd(M, D, seed=3)
+    Ws = [rnd(D, D, seed=10 + i, scale=0.6 * D ** -0.5) for i in range(3)]
+    b1, b2 = 0.3 * torch.randn(D, device="cuda"), 0.3 * torch.randn(D, device="cuda")
+    f = lambda t: t.float()
+    mm = lambda a, w: f(a) @ f(w).t()
+    # linear, one pair, bias scaled by R (model.py:75: n = W_p(sum_j A_ij h_j) + R b_p)
+    close(ops.gemm([(n, Ws[0])], bias=b1, bias_scale=6.0), mm(n, Ws[0]) + 6.0 * b1)
+    # linear + residual + ReLU, three pairs (the backward's dn GEMM has three: model.py:80-83 transposed)
+    res = rnd(M, D, seed=4)
+    pre3 = mm(n, Ws[0]) + mm(h, Ws[1]) + mm(rh, Ws[2])
+    close(ops.gemm([(n, Ws[0]), (h, Ws[1]), (rh, Ws[2])], bias=b1, bias2=b2, res=res, act=ops.ACT_RELU),
+          F.relu(pre3 + b1 + b2 + f(res)))
+    # z = sigmoid(W_z n + U_z h)                                                 model.py:80
+    pre2 = mm(n, Ws[0]) + mm(h, Ws[1]) + b1 + b2
+    close(ops.gemm([(n, Ws[0]), (h, Ws[1])], bias=b1, bias2=b2, act=ops.ACT_SIGMOID), torch.sigmoid(pre2))
+    close(ops.gemm([(n, Ws[0]), (h, Ws[1])], bias=b1, bias2=b2, act=ops.ACT_TANH), torch.tanh(pre2))
+    # r = sigmoid(W_r n + U_r h), r*h                                            model.py:81,83
+    r, rmul = ops.gemm([(n, Ws[0]), (h, Ws[1])], bias=b1, bias2=b2, act=ops.ACT_SIGMOID_MUL, aux1=h)
+    close(r, torch.sigmoid(pre2))
+    close(rmul, torch.sigmoid(pre2) * f(h))
+    # c = tanh(W_h n + U_h (r*h)), h' = (1-z) h + z c                            model.py:82-84
+    z = torch.rand(M, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9)).to(BF)
+    pre_c = mm(n, Ws[0]) + mm(rh, Ws[2]) + b1 + b2
+    hn, c = ops.gemm([(n, Ws[0]), (rh, Ws[2])], bias=b1, bias2=b2, act=ops.ACT_TANH_BLEND, aux1=h, aux2=z)
+    close(c, torch.tanh(pre_c))
+    close(hn, (1 - f(z)) * f(h) + f(z) * torch.tanh(pre_c))
+    # fp32 output (classifier logits: model.py:152,168), N = 2001 -> ragged last column tile
+    Wc = rnd(2001, D, seed=20, scale=D ** -0.5)
+    out = ops.gemm([(n, Wc)], bias=b1[:2001].contiguous(), out_f32=True)
+    assert out.dtype == torch.float32
+    ref = mm(n, Wc) + b1[:2001]
+    assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max()) * 8

@@ -75,13 +75,36 @@ def test_train_crops_stay_inside_the_image_and_flip(shard_dir):
 
 
 def test_ranks_partition_the_epoch(shard_dir):
+    """Training shards: every rank gets the SAME number of samples and batches (the epoch's permutation is padded by
+    wrapping, as DistributedSampler does) -- a rank with one batch more than its peers would block in the gradient
+    all-reduce forever -- and together the ranks cover every sample.  Evaluation shards: unpadded, every sample once."""
     _, out, names, ann = shard_dir
     enc = imsitu_encoder(ann, quiet=True)
-    got = []
-    for r in range(2):
-        dl = sh.ShardLoader(out, ann, enc, batch_size=2, device="cpu", train=True, rank=r, world=2, seed=5)
-        got.append([n for nm, *_ in dl for n in nm])
-    assert sorted(got[0] + got[1]) == sorted(names) and not set(got[0]) & set(got[1])
+    N = len(names)
+    for world, bs in ((2, 2), (3, 1), (3, 2), (4, 3)):
+        got, lens = [], []
+        for r in range(world):
+            dl = sh.ShardLoader(out, ann, enc, batch_size=bs, device="cpu", train=True, rank=r, world=world, seed=5)
+            batches = [list(nm) for nm, *_ in dl]
+            assert len(batches) == len(dl)
+            lens.append([len(b) for b in batches])
+            got.append([n for b in batches for n in b])
+        assert all(l == lens[0] for l in lens), (world, bs, lens)          # same batch count AND sizes on every rank
+        per = -(-N // world)
+        assert all(len(g) == per for g in got)
+        assert set(sum(got, [])) == set(names)
+        assert len(sum(got, [])) - len(set(sum(got, []))) == per * world - N   # only the wrap-around padding repeats
+        ev = []
+        for r in range(world):
+            dl = sh.ShardLoader(out, ann, enc, batch_size=bs, device="cpu", train=False, rank=r, world=world)
+            ev += [n for nm, *_ in dl for n in nm]
+        assert sorted(ev) == sorted(names)
+    # set_epoch selects the permutation (same contract as DistributedSampler.set_epoch)
+    dl = sh.ShardLoader(out, ann, enc, batch_size=2, device="cpu", train=True, rank=0, world=1, seed=5)
+    dl.set_epoch(3); a = [n for nm, *_ in dl for n in nm]
+    dl.set_epoch(3); b = [n for nm, *_ in dl for n in nm]
+    dl.set_epoch(4); c = [n for nm, *_ in dl for n in nm]
+    assert a == b and sorted(a) == sorted(c) == sorted(names)
 
 
 def test_driver_writes_shards_without_a_gpu(shard_dir, tmp_path):
