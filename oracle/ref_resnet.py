@@ -128,3 +128,23 @@ def perturb_batchnorm_(net, seed):
                 m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
                 m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
     return net
+
+
+def calibrate_batchnorm_(net, img):
+    """Set every BatchNorm's running statistics to the batch statistics of `img` (one train-mode pass with momentum 1).
+    A He-initialised net with arbitrary running statistics is not normalised in eval mode: activations grow by orders of
+    magnitude through 50 residual blocks and absolute tolerances on its logits mean nothing.  A TRAINED net's running
+    statistics are the statistics of its activations -- this puts a randomly initialised test net into that regime."""
+    bns = [m for m in net.modules() if isinstance(m, nn.BatchNorm2d)]
+    keep = [(m.momentum, m.training) for m in bns]
+    was = net.training
+    net.train()
+    for m in bns:
+        m.momentum = 1.0
+    with torch.no_grad():
+        net(img)
+    for m, (mom, _) in zip(bns, keep):
+        m.momentum = mom
+        m.num_batches_tracked.zero_()
+    net.train(was)
+    return net
