@@ -47,6 +47,17 @@ inline bool sr_set_dynamic_lds(int bytes) {
   __atomic_store_n(&done[d], 1u, __ATOMIC_RELEASE);
   return true;
 }
+// the same, keyed by a tag type (for kernels hipcc cannot take as a non-type template argument on the host side)
+template <typename Tag>
+inline bool sr_set_dynamic_lds_tagged(const void* kernel, int bytes) {
+  static unsigned done[SR_MAX_DEV] = {};
+  const int d = sr_cur_dev();
+  if (d < 0) return false;
+  if (__atomic_load_n(&done[d], __ATOMIC_ACQUIRE)) return true;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  __atomic_store_n(&done[d], 1u, __ATOMIC_RELEASE);
+  return true;
+}
 inline int sr_num_cus() {
   static int cache[SR_MAX_DEV] = {};
   const int d = sr_cur_dev();
@@ -58,6 +69,9 @@ inline int sr_num_cus() {
   }
   return n;
 }
+
+// expand.hip: the output-heavy 1x1 convolutions (internal hand-over from sr_conv2d; SR_ERR_UNSUPPORTED = not one of its shapes)
+int srx_conv1x1_expand(const sr_conv_args* a, long M, void* stream);
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }

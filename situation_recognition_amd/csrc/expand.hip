@@ -1,0 +1,339 @@
+// Output-heavy 1x1 convolution (bottleneck expansion / eval-mode folded expansion) for gfx950:
+//
+//     out[M,N] = relu?( (A[M,K] . W[N,K]^T) * escale[n] + bias[n] (+ res[M,N]) )        bf16 in / out, fp32 accumulate
+//
+// with K in {64,128,256} and N = a multiple of 256 (ResNet: N = 4K).  Per output element the kernel moves 2 B of output,
+// 2 B of residual and 0.5 B of A through HBM against 2K FLOPs: it is HBM-bound (layer3: 4.9 GB of residual + output per launch),
+// and the generic 256x256 kernel of gemm.hip runs its K loop (matrix cores busy, HBM idle) and its epilogue (HBM busy, matrix
+// cores idle) one after the other: measured 1500 us = 600 (K loops) + 900 (the epilogue's memory floor).
+//
+// Here the two overlap inside one workgroup:
+//   * tile 128 x 256, 8 waves as 2 x 4, each wave 64 x 64 = 4 x 4 fragments of v_mfma_f32_16x16x32_bf16: 64 accumulator
+//     registers -- so TWO accumulator sets fit where the 256x256 tile had one;
+//   * while the K loop of tile t accumulates into one set, the epilogue of tile t-1 drains the other, cut into 8 half-strips
+//     (8 rows x 64 columns per wave) that are spread over the K-steps of tile t: fragments -> per-wave fp32 staging strip in
+//     LDS (XOR swizzle) -> rows of 8 consecutive columns per lane -> scale/shift FMA, residual add, ReLU, one 16-byte store;
+//   * a workgroup walks all N/256 column tiles of one 128-row block before it moves on (A re-reads hit L2, its stores cover whole
+//     output rows within a few microseconds);
+//   * ONE instruction stream for every tile, including a dummy epilogue in front of the first tile and a dummy K loop behind the
+//     last one (their buffer descriptors have num_records = 0: loads return zeros, stores are dropped, but every operation is
+//     issued), so the number of vector-memory operations between any two points of the stream is a compile-time constant and
+//     every wait is a COUNTED vmcnt: LDS-DMA pieces, residual loads and output stores all retire in issue order (CDNA4) and
+//     none of them ever drains the queue.
+//
+// LDS (N <= 1024): 5 ring slots x 24 KiB (A 128 rows + W 256 rows of 64 bytes per K-step) + 8 x 4 KiB staging + 8 KiB of
+// escale/bias = exactly 160 KiB.  Row swizzle / fragment reads as in gemm.hip's v3 kernels.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+struct ExpArgs {
+  const bf16_t* A; long lda;
+  const bf16_t* W; long ldw;
+  const bf16_t* res; long ldres;
+  bf16_t* out; long ldc;
+  const float* escale; const float* bias;
+  int M, N, K, relu;
+  int debug;   // SR_EXPAND_DEBUG bits (diagnostic timing only, results are garbage): 1 no MFMA, 2 no epilogue arithmetic, 4 no residual loads / stores, 8 no LDS-DMA
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {       // f(std::integral_constant<int, I>) for I .. N-1: indices usable as template arguments
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int N> __device__ __forceinline__ void xwait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int XSLOT = 24576;      // one K-step: A 128 x 64 B, then W 256 x 64 B
+constexpr int XSTG = 4096;        // per-wave staging strip: 16 rows x 64 columns fp32
+constexpr int XOOB = (int)0x80000000;
+constexpr int XNREC = 0x7ffff000;
+
+// half-strips of the previous tile's epilogue that ride on K-step `u` of the current tile (8 per tile)
+template <int NKT> constexpr int hs_count(int u) { return NKT == 16 ? (u & 1) : 8 / NKT; }
+template <int NKT> constexpr int hs_first(int u) { return NKT == 16 ? u / 2 : u * (8 / NKT); }
+// vector-memory operations issued after the LDS-DMA pieces of K-step s (issued D steps earlier) and before the wait for them
+template <int NKT, int D, int OPS> constexpr int younger_than_dma(int s) {
+  int n = (D - 1) * 3;
+  for (int u = s - D; u < s; ++u) n += OPS * hs_count<NKT>(((u % NKT) + NKT) % NKT);
+  return n;
+}
+
+template <int NKT, int NSLOT, bool RES>
+__device__ __forceinline__ void expand_body(const ExpArgs& p) {
+  constexpr int D = NSLOT - 1;
+  static_assert(D >= 1 && D <= NKT, "the loader runs at most one tile ahead");
+  constexpr int OPS = RES ? 2 : 1;                 // vector-memory operations per half-strip: one store (+ one residual load)
+  constexpr int PERIOD = 3 * NKT + 8 * OPS;        // ... per tile
+  static_assert(PERIOD - 2 < 64, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const stg_base = smem + NSLOT * XSLOT;
+  float* const vec = reinterpret_cast<float*>(stg_base + 8 * XSTG);   // [2][N]: escale, bias
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const int fsw = ((lane >> 4) ^ ((lane & 8) >> 2)) << 4;   // fragment read: byte offset of this lane's 16-byte k-chunk in a 64-B row
+
+  const int gn = p.N >> 8;
+  const int nblk = (p.M + 127) >> 7;
+  const int G = gridDim.x;
+  int vb = blockIdx.x;
+  {
+    const int xcd = vb & 7, q = G >> 3, r = G & 7;
+    vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+  }
+  const int my_blocks = vb < nblk ? (nblk - vb + G - 1) / G : 0;
+  const int tiles_mine = my_blocks * gn;
+
+  // per-column vectors of the whole launch -> LDS (read back per tile with ds_read: no vector-memory operation in the stream)
+  for (int i = threadIdx.x; i < p.N; i += 512) {
+    vec[i] = p.escale ? p.escale[i] : 1.f;
+    vec[p.N + i] = p.bias ? p.bias[i] : 0.f;
+  }
+
+  // ---------------- loader ----------------
+  // piece = 16 rows x 64 B per wave-instruction (lane -> row l>>2, 16-byte chunk l&3 of the swizzled row image)
+  const int prow = lane >> 2;
+  const int ec = ((lane & 3) ^ ((lane >> 5) << 1)) * 8;                 // source element offset of the chunk this lane stores
+  const int a_row = wave * 16 + prow;                                    // A piece `wave`: rows wave*16 .. +15 of the 128
+  const int a_vo_ok = (int)((a_row * p.lda + ec) * 2);
+  int w_vo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) w_vo[i] = (int)((((wave + i * 8) * 16 + prow) * p.ldw + ec) * 2);
+  char* const a_dst = smem + wave * 1024;
+  char* const w_dst0 = smem + 8192 + wave * 1024;
+  char* const w_dst1 = smem + 8192 + (wave + 8) * 1024;
+
+  struct Desc { __amdgpu_buffer_rsrc_t a, w; int a_vo; };
+  auto make_desc = [&](int blk, int tn, bool valid) {
+    Desc d;
+    const long m0 = (long)blk * 128;
+    d.a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + m0 * p.lda), 0, valid ? XNREC : 0, 0x00020000);
+    d.w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long)tn * 256 * p.ldw), 0, valid ? XNREC : 0, 0x00020000);
+    d.a_vo = (m0 + a_row < p.M) ? a_vo_ok : XOOB;
+    return d;
+  };
+  auto issue = [&](const Desc& d, int kstep, int slot) {
+    const int so = kstep * 64;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(d.a, (__attribute__((address_space(3))) void*)(a_dst + slot * XSLOT), 16, d.a_vo, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(d.w, (__attribute__((address_space(3))) void*)(w_dst0 + slot * XSLOT), 16, w_vo[0], so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(d.w, (__attribute__((address_space(3))) void*)(w_dst1 + slot * XSLOT), 16, w_vo[1], so, 0, 0);
+  };
+
+  // ---------------- epilogue addressing (row layout: lane -> row lane/8 of a half-strip, columns (lane%8)*8 .. +7) ----------------
+  const int rrow = lane >> 3, rq8 = lane & 7;
+  const int o_vo = (int)((((wm * 64 + rrow) * p.ldc) + wn * 64 + rq8 * 8) * 2);
+  const int r_vo = (int)((((wm * 64 + rrow) * p.ldres) + wn * 64 + rq8 * 8) * 2);
+  const int o_step = (int)(8 * p.ldc * 2), r_step = (int)(8 * p.ldres * 2);      // bytes from one half-strip to the next
+  char* const stg = stg_base + wave * XSTG;
+  // staging strip: row r (256 B), 16-byte chunk c stored at chunk position c ^ r
+  const int stg_w = frow * 256;                                  // + ((j*4 + fgrp) ^ frow) * 16
+  struct OutDesc { __amdgpu_buffer_rsrc_t o, r; int n0; };
+  auto make_out = [&](int blk, int tn, bool valid) {
+    OutDesc d;
+    const long m0 = (long)blk * 128;
+    const long rows = valid ? ((long)p.M - m0 < 128 ? (long)p.M - m0 : 128) : 0;
+    const int n0 = tn * 256;
+    // a row at or beyond `rows` starts at or beyond num_records (ldc >= 256): its store is dropped, its residual reads as zero
+    d.o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + m0 * p.ldc + n0), 0, rows > 0 ? (int)(((rows - 1) * p.ldc + 256) * 2) : 0, 0x00020000);
+    d.r = __builtin_amdgcn_make_buffer_rsrc((void*)((RES ? p.res : p.out) + m0 * p.ldres + n0), 0,
+                                            (RES && rows > 0) ? (int)(((rows - 1) * p.ldres + 256) * 2) : 0, 0x00020000);
+    d.n0 = n0;
+    return d;
+  };
+
+  f32x4_t acc[2][4][4];   // [set][n-fragment j][m-fragment i]
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[s][j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  uint4 rq[8];            // residual chunks of the tile whose K loop is running, one per half-strip
+#pragma unroll
+  for (int e = 0; e < 8; ++e) rq[e] = make_uint4(0, 0, 0, 0);
+
+  const int a_off = (wm * 64 + frow) * 64 + fsw;
+  const int b_off = 8192 + (wn * 64 + frow) * 64 + fsw;
+
+  // tile ordinal q -> (block, column tile)
+  int blk_c = vb, tn_c = 0;                 // tile whose K loop runs in the current iteration
+  Desc ld_c = make_desc(blk_c, tn_c, tiles_mine > 0);
+  OutDesc out_c = make_out(blk_c, tn_c, tiles_mine > 0);
+  OutDesc out_p = make_out(0, 0, false);    // tile being drained: none yet
+  // prologue: the first D K-steps of tile 0; drained completely once, so that the counted waits below start from a known state
+#pragma unroll
+  for (int s = 0; s < D; ++s) issue(ld_c, s, s);
+  xwait_vm<0>();
+  __syncthreads();
+
+  int slot_c = 0, slot_i = D % NSLOT;       // ring slot read by the next K-step / filled by the next issue
+
+  auto body = [&](auto CURC, int it) {
+    constexpr int CUR = decltype(CURC)::value, PRV = 1 - CUR;
+    // descriptors of the next tile (the loader crosses into it D steps before this tile's K loop ends)
+    int blk_n = blk_c, tn_n = tn_c + 1;
+    if (tn_n == gn) { tn_n = 0; blk_n += G; }
+    const bool valid_n = it + 1 < tiles_mine;
+    const Desc ld_n = make_desc(blk_n, tn_n, valid_n);
+    // per-column vectors of the tile being drained
+    float esc[8], bia[8];
+    {
+      const float* e0 = vec + out_p.n0 + wn * 64 + rq8 * 8;
+      const float4 a = *reinterpret_cast<const float4*>(e0), b = *reinterpret_cast<const float4*>(e0 + 4);
+      const float4 c = *reinterpret_cast<const float4*>(e0 + p.N), d = *reinterpret_cast<const float4*>(e0 + p.N + 4);
+      esc[0] = a.x; esc[1] = a.y; esc[2] = a.z; esc[3] = a.w; esc[4] = b.x; esc[5] = b.y; esc[6] = b.z; esc[7] = b.w;
+      bia[0] = c.x; bia[1] = c.y; bia[2] = c.z; bia[3] = c.w; bia[4] = d.x; bia[5] = d.y; bia[6] = d.z; bia[7] = d.w;
+    }
+    static_for<0, NKT>([&](auto SC) {
+      constexpr int s = decltype(SC)::value;
+      xwait_vm<younger_than_dma<NKT, D, OPS>(s)>();            // my pieces of K-step s have landed
+      __builtin_amdgcn_s_barrier();                            // everybody's have; everybody has read K-step s-1
+      asm volatile("" ::: "memory");
+      if (!(p.debug & 8)) { if (s + D < NKT) issue(ld_c, s + D, slot_i); else issue(ld_n, s + D - NKT, slot_i); }
+      slot_i = slot_i + 1 == NSLOT ? 0 : slot_i + 1;
+      bf16x8_t fa[4], fb[4];
+      const char* sl = smem + slot_c * XSLOT;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(sl + b_off + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sl + a_off + i * 1024);
+      slot_c = slot_c + 1 == NSLOT ? 0 : slot_c + 1;
+      if (!(p.debug & 1)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[CUR][j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[CUR][j][i], 0, 0, 0);
+      }
+      // ---- half-strips of the previous tile's epilogue that ride on this K-step
+      static_for<0, hs_count<NKT>(s)>([&](auto KC) {
+        constexpr int e = hs_first<NKT>(s) + decltype(KC)::value, i = e >> 1, h = e & 1;
+        if (p.debug & 2) {
+          if (!(p.debug & 4)) {
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0, 0, 0, 0}, out_p.o, o_vo, e * o_step, 0);
+            if (RES) { const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(out_c.r, r_vo, e * r_step, 0); rq[e] = make_uint4(t[0], t[1], t[2], t[3]); }
+          }
+          return;
+        }
+        if (h == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4_t*>(stg + stg_w + (((j * 4 + fgrp) ^ frow) << 4)) = acc[PRV][j][i];
+        }
+        const int r16 = h * 8 + rrow;
+        const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(stg + r16 * 256 + (((2 * rq8) ^ r16) << 4));
+        const f32x4_t x1 = *reinterpret_cast<const f32x4_t*>(stg + r16 * 256 + (((2 * rq8 + 1) ^ r16) << 4));
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          v[c] = __builtin_fmaf(x0[c], esc[c], bia[c]);
+          v[4 + c] = __builtin_fmaf(x1[c], esc[4 + c], bia[4 + c]);
+        }
+        if (RES) {
+          xwait_vm<PERIOD - 2>();                              // the chunk requested one tile ago (everything older has retired)
+          const unsigned* pr = reinterpret_cast<const unsigned*>(&rq[e]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            v[2 * c] += __uint_as_float(pr[c] << 16);
+            v[2 * c + 1] += __uint_as_float(pr[c] & 0xffff0000u);
+          }
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) asm("v_max_f32 %0, 0, %1" : "=v"(v[c]) : "v"(v[c]));
+        }
+        bf16_t pk[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pk[c] = (bf16_t)v[c];
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        if (p.debug & 4) return;
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t*>(pk), out_p.o, o_vo, e * o_step, 0);
+        if (RES) {
+          const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(out_c.r, r_vo, e * r_step, 0);
+          rq[e] = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+      });
+    });
+    // the drained set starts the next tile from zero
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[PRV][j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    out_p = out_c;
+    blk_c = blk_n; tn_c = tn_n;
+    ld_c = ld_n;
+    out_c = make_out(blk_c, tn_c, valid_n);
+  };
+
+  // iteration `it`: K loop of tile it (dummy when it == tiles_mine), epilogue of tile it-1 (dummy when it == 0)
+  for (int it = 0; it <= tiles_mine; it += 2) {
+    body(std::integral_constant<int, 0>{}, it);
+    if (it + 1 <= tiles_mine) body(std::integral_constant<int, 1>{}, it + 1);
+  }
+  xwait_vm<0>();
+}
+
+// (thin kernel around a __device__ body: with the generic lambdas inside the __global__ function itself hipcc's HOST pass
+//  silently drops the kernel's launch stub and the library no longer links)
+template <int NKT, int NSLOT, bool RES>
+__global__ __launch_bounds__(512, 2) void conv1x1_expand_kernel(const ExpArgs p) { expand_body<NKT, NSLOT, RES>(p); }
+
+inline bool expand_enabled() {
+  static const bool off = [] { const char* e = getenv("SR_NO_EXPAND"); return e && e[0] == '1'; }();
+  return !off;
+}
+
+template <int NKT, int NSLOT, bool RES> struct XTag {};
+
+template <int NKT, int NSLOT>
+int launch_expand(const ExpArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)NSLOT * XSLOT + 8 * XSTG + (size_t)a.N * 8;
+  const int nblk = (a.M + 127) / 128, cus = sr_num_cus();
+  const unsigned grid = (unsigned)(nblk < cus ? nblk : cus);
+  if (a.res) {
+    if (!sr_set_dynamic_lds_tagged<XTag<NKT, NSLOT, true>>(reinterpret_cast<const void*>(&conv1x1_expand_kernel<NKT, NSLOT, true>), (int)lds)) return SR_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv1x1_expand_kernel<NKT, NSLOT, true>), dim3(grid), dim3(512), lds, st, a);
+  } else {
+    if (!sr_set_dynamic_lds_tagged<XTag<NKT, NSLOT, false>>(reinterpret_cast<const void*>(&conv1x1_expand_kernel<NKT, NSLOT, false>), (int)lds)) return SR_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv1x1_expand_kernel<NKT, NSLOT, false>), dim3(grid), dim3(512), lds, st, a);
+  }
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
+}  // namespace
+
+// Internal (not part of include/srhip.h): sr_conv2d hands over the launches this kernel serves.  Returns SR_ERR_UNSUPPORTED
+// when the shape is not one of them (the caller then uses the generic kernel).
+int srx_conv1x1_expand(const sr_conv_args* a, long M, void* stream) {
+  if (!expand_enabled()) return SR_ERR_UNSUPPORTED;
+  if (a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->stem || a->stats || a->no_store) return SR_ERR_UNSUPPORTED;
+  if (a->Cout % 256 || a->Cout > 1024 || (a->Cin != 64 && a->Cin != 128 && a->Cin != 256)) return SR_ERR_UNSUPPORTED;
+  if (M < 128 * 256 || M > 0x7fffffffL) return SR_ERR_UNSUPPORTED;      // (small launches: the generic kernel's narrow tiles fill the chip better)
+  if ((long)128 * a->Cout * 2 >= 0x7fffffffL) return SR_ERR_UNSUPPORTED;
+  ExpArgs x;
+  x.A = (const bf16_t*)a->x; x.lda = a->Cin;
+  x.W = (const bf16_t*)a->w; x.ldw = a->Cin;
+  x.res = (const bf16_t*)a->res; x.ldres = a->Cout;
+  x.out = (bf16_t*)a->y; x.ldc = a->Cout;
+  x.escale = a->escale; x.bias = a->bias;
+  x.M = (int)M; x.N = a->Cout; x.K = a->Cin; x.relu = a->act == SR_ACT_RELU;
+  static const int dbg = [] { const char* e = getenv("SR_EXPAND_DEBUG"); return e ? atoi(e) : 0; }();
+  x.debug = dbg;
+  hipStream_t st = (hipStream_t)stream;
+  switch (a->Cin) {
+    case 64: return launch_expand<2, 3>(x, st);
+    case 128: return launch_expand<4, 5>(x, st);
+    default: return launch_expand<8, 5>(x, st);
+  }
+}

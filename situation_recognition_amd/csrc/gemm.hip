@@ -1409,6 +1409,10 @@ extern "C" int sr_conv2d(const sr_conv_args* a, int dtype, void* stream) {
   const long M = (long)a->B * Ho * Wo;
   if (M <= 0 || M > 0x7fffffffL) return SR_ERR_ARG;
   if (a->act != SR_ACT_NONE && a->act != SR_ACT_RELU) return SR_ERR_ARG;
+  if (dtype == SR_BF16 && use_v3()) {     // output-heavy 1x1 convolutions: the kernel that overlaps K loop and epilogue (expand.hip)
+    const int rc = srx_conv1x1_expand(a, M, stream);
+    if (rc != SR_ERR_UNSUPPORTED) return rc;
+  }
   k.kp[0].A = a->x; k.kp[0].W = a->w; k.kp[0].lda = 0; k.kp[0].ldw = k.kp[0].K;
   k.nk[0] = k.kp[0].K / bk;
   k.npairs = 1; k.M = (int)M; k.N = a->Cout; k.act = a->act;

@@ -177,3 +177,26 @@ def test_gemm_2048_all_epilogues_on_the_ping_pong_kernel(ops, M):
     assert out.dtype == torch.float32
     ref = mm(n, Wc) + b1[:2001]
     assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max()) * 8
+
+
+@pytest.mark.parametrize("Cin,Cout,rows", [(64, 256, 40000), (128, 512, 33000), (256, 1024, 32768 + 77), (256, 256, 50001), (128, 768, 36000)])
+def test_expand_kernel_options_and_ragged_rows(ops, Cin, Cout, rows):
+    """`conv1x1_expand_kernel` (csrc/expand.hip: 128x256 tiles, two accumulator sets, the previous tile's epilogue riding on the
+    current tile's K-steps): every K variant (64 / 128 / 256), row counts that are not a multiple of the 128-row block
+    (the tail rows are dropped by the buffer descriptor's range check, their A rows read as zeros), with and without
+    multiplier / bias / residual / ReLU -- against the fp32 matmul; a sentinel behind the last row must survive."""
+    import os
+    x = rnd(1, rows, 1, Cin, seed=rows)
+    w = rnd(Cout, Cin, 1, 1, seed=Cin, scale=Cin ** -0.5)
+    idn = rnd(1, rows, 1, Cout, seed=Cout)
+    esc, bias = 0.5 + torch.rand(Cout, device="cuda"), 0.3 * torch.randn(Cout, device="cuda")
+    base = x.float().view(rows, Cin) @ w.float().view(Cout, Cin).t()
+    sentinel = torch.full((1, rows + 64, 1, Cout), 7.0, device="cuda", dtype=BF)
+    for use_esc, use_bias, use_res, relu in ((1, 1, 1, 1), (0, 1, 1, 1), (1, 1, 0, 0), (0, 0, 0, 0), (0, 1, 0, 1), (1, 0, 1, 0)):
+        ref = base * (esc if use_esc else 1.0) + (bias if use_bias else 0.0) + (idn.float().view(rows, Cout) if use_res else 0.0)
+        ref = F.relu(ref) if relu else ref
+        out = sentinel.clone()
+        y = ops.conv2d(x, pack_w(w), Cout, 1, 1, 0, bias=bias if use_bias else None, escale=esc if use_esc else None,
+                       res=idn if use_res else None, relu=bool(relu), out=out[:, :rows])
+        close(y.view(rows, Cout), ref)
+        assert float((out[:, rows:].float() - 7.0).abs().max()) == 0.0          # nothing written past the last row
