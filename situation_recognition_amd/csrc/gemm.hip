@@ -1217,7 +1217,10 @@ int launch_v3e(const KArgs& k, unsigned grid, size_t lds, hipStream_t st) {
 struct V3Plan { long grid, gn, nflush, rows; };
 inline V3Plan v3_plan(long M, int N, int cfg, bool stats) {
   const int BN = 64 * cfg, wg_per_cu = cfg == 4 ? 1 : 2, waves_m = cfg == 1 ? 4 : 2;
-  const long gm = (M + 255) / 256, gn = (N + BN - 1) / BN, ntiles = gm * gn, cap = (long)num_cus() * wg_per_cu;
+  // SR_GEMM_HALF=1 (experiment: two streams sharing every CU): one workgroup per CU also for the 4-wave tiles, so that a
+  // kernel of another stream finds half of every CU's registers and LDS free
+  static const bool half = [] { const char* e = getenv("SR_GEMM_HALF"); return e && e[0] == '1'; }();
+  const long gm = (M + 255) / 256, gn = (N + BN - 1) / BN, ntiles = gm * gn, cap = (long)num_cus() * (half ? 1 : wg_per_cu);
   V3Plan pl{ntiles < cap ? ntiles : cap, gn, 0, 0};
   if (stats) {
     if (pl.grid >= gn) pl.grid -= pl.grid % gn; else pl.grid = gn;

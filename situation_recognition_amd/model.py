@@ -196,6 +196,7 @@ class resnet(nn.Module):
         self._stats_epoch = 0          # bumped whenever a train-mode pass changed running statistics
         self._pending_tracked = 0      # num_batches_tracked increments not yet written to the buffers
         self._gram_stash = None        # (data_ptr, Gram partials) a fused BN-apply left for the expansion conv that follows
+        self._unit_hook, self._unit_count = None, 0   # (n, fn): fn() is called before this backbone's n-th conv unit of a pass
         self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_counters())
         self.register_load_state_dict_post_hook(lambda m, incompatible: m._after_load())
 
@@ -253,6 +254,11 @@ class resnet(nn.Module):
         """`then`: the unit that consumes this one's output next (lets BN-apply and the consumer's Gram pass share one sweep).
         `twin` = (unit of a weight-identical backbone, its momentum): its running statistics are updated from the same batch."""
         dt = self.dtype
+        hook = self._unit_hook
+        if hook is not None:                            # (FCGGNN.forward: phase offset between the two backbones' streams)
+            self._unit_count += 1
+            if self._unit_count == hook[0]:
+                hook[1]()
         if not train:
             w, b = u.folded(dt, self._stats_epoch)
             y = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=b, res=res, relu=relu, stem_hw=stem_hw)
@@ -704,10 +710,25 @@ class FCGGNN(nn.Module):
             if side is None:
                 side = self._side_streams[img.device] = torch.cuda.Stream(device=img.device)
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                feat = self.convnet_nouns(img, bn_updates=2)
-            img.record_stream(side)
-            pred_verb = self.predict_verb(img, batch_size)
+            phase = int(os.environ.get("SR_PHASE_UNITS", "0"))
+            if phase > 0:
+                # the noun backbone starts `phase` conv units behind the verb backbone, so that one stream's matrix-bound 3x3
+                # convolutions run beside the other's HBM-bound kernels.  The host enqueues the noun pass first (its stream
+                # waits for the event) -- the event itself is recorded while the verb pass is being enqueued.
+                ev = torch.cuda.Event()
+                self.convnet_verbs._unit_count = 0
+                self.convnet_verbs._unit_hook = (phase, lambda: ev.record(main))
+                pred_verb = self.predict_verb(img, batch_size)
+                self.convnet_verbs._unit_hook = None
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    feat = self.convnet_nouns(img, bn_updates=2)
+                img.record_stream(side)
+            else:
+                with torch.cuda.stream(side):
+                    feat = self.convnet_nouns(img, bn_updates=2)
+                img.record_stream(side)
+                pred_verb = self.predict_verb(img, batch_size)
             main.wait_stream(side)
             feat.record_stream(main)
         else:
