@@ -60,5 +60,17 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_stamps():
+    """Diagnostic library with in-kernel cycle stamps in expand.hip (libsrhip_stamps.so; select it with SR_LIB_PATH)."""
+    build(verbose=False)
+    hipcc = _hipcc()
+    obj = os.path.join(OBJ, "expand_stamps.o")
+    subprocess.run([hipcc] + FLAGS + ["-DXSTAMPS", "-c", os.path.join(HERE, "expand.hip"), "-o", obj], check=True)
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s != "expand.hip"] + [obj]
+    out = os.path.join(PKG, "libsrhip_stamps.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_stamps() if "--stamps" in sys.argv else build(force="--force" in sys.argv))

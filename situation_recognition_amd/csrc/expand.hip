@@ -38,7 +38,6 @@ struct ExpArgs {
   bf16_t* out; long ldc;
   const float* escale; const float* bias;
   int M, N, K, relu;
-  int debug;   // SR_EXPAND_DEBUG bits (diagnostic timing only, results are garbage): 1 no MFMA, 2 no epilogue arithmetic, 4 no residual loads / stores, 8 no LDS-DMA
 };
 
 template <int I, int N, typename F>
@@ -66,7 +65,18 @@ template <int NKT, int D, int OPS> constexpr int younger_than_dma(int s) {
   return n;
 }
 
-template <int NKT, int NSLOT, bool RES>
+#ifdef XSTAMPS
+// Diagnostic build only (build.py --stamps -> libsrhip_stamps.so): per-wave sums of s_memtime deltas over the sections of a K-step.
+//   0 wait vmcnt + barrier, 1 LDS-DMA issue, 2 fragment reads (+ wait), 3 MFMAs, 4 staging write/read (+ wait), 5 epilogue
+//   arithmetic, 6 store + residual load issue, 7 K-steps
+__device__ unsigned long long g_xstamps[256 * 8 * 8];
+#define XSTAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#define XACC(k) do { unsigned long long t_; XSTAMP(t_); xs[k] += t_ - xt; xt = t_; } while (0)
+#else
+#define XACC(k) do {} while (0)
+#endif
+
+template <int NKT, int NSLOT, bool RES, bool RELU, bool PP>
 __device__ __forceinline__ void expand_body(const ExpArgs& p) {
   constexpr int D = NSLOT - 1;
   static_assert(D >= 1 && D <= NKT, "the loader runs at most one tile ahead");
@@ -175,8 +185,24 @@ __device__ __forceinline__ void expand_body(const ExpArgs& p) {
   for (int s = 0; s < D; ++s) issue(ld_c, s, s);
   xwait_vm<0>();
   __syncthreads();
+  // The two wave groups (wm = 0 / 1: one wave of each on every SIMD) run HALF A STEP apart: while one group is in its L section
+  // (LDS-DMA issue, fragment reads, staging round trip) the other is in its M section (MFMAs, epilogue arithmetic, store), each
+  // section closed by a barrier.  In lock-step all eight waves hit the LDS at once and then all hit the matrix pipe at once:
+  // in-kernel stamps showed 700 cycles per step for the LDS burst alone and 2200-2800 cycles per step in all.
+  //   DMA-after-read : L(s) refills the slot of K-step s-1, whose fragments both groups had in registers (lgkmcnt 0) before a
+  //                    barrier both have passed (group 0: B1(s-1); group 1: its B1(s-1) = group 0's B2(s-1)).
+  //   read-after-DMA : group 0 reads K-step s+1 in the section after its M(s), group 1 one section later; every wave has waited
+  //                    for its own pieces of K-step s+1 before the barrier in front of group 0's read (group 0 at the end of
+  //                    M(s), group 1 at the end of its L(s), the same time slot).
+  // PP is chosen per shape by measurement (layer2's K = 128: 2054 us against 2470 in lock-step; K = 256 and K = 64 lose: with
+  // four waves in every section the LDS burst halves but the LDS-DMA issue backs up behind the other group's stores).
+  if (PP && wm == 1) __builtin_amdgcn_s_barrier();
 
   int slot_c = 0, slot_i = D % NSLOT;       // ring slot read by the next K-step / filled by the next issue
+#ifdef XSTAMPS
+  unsigned long long xs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt;
+  XSTAMP(xt);
+#endif
 
   auto body = [&](auto CURC, int it) {
     constexpr int CUR = decltype(CURC)::value, PRV = 1 - CUR;
@@ -196,11 +222,20 @@ __device__ __forceinline__ void expand_body(const ExpArgs& p) {
     }
     static_for<0, NKT>([&](auto SC) {
       constexpr int s = decltype(SC)::value;
-      xwait_vm<younger_than_dma<NKT, D, OPS>(s)>();            // my pieces of K-step s have landed
-      __builtin_amdgcn_s_barrier();                            // everybody's have; everybody has read K-step s-1
-      asm volatile("" ::: "memory");
-      if (!(p.debug & 8)) { if (s + D < NKT) issue(ld_c, s + D, slot_i); else issue(ld_n, s + D - NKT, slot_i); }
+      if (!PP) {
+        xwait_vm<younger_than_dma<NKT, D, OPS>(s)>();          // lock-step form: my pieces of K-step s have landed
+        __builtin_amdgcn_s_barrier();                          // everybody's have; everybody has read K-step s-1
+        asm volatile("" ::: "memory");
+        XACC(0);
+      }
+      // ---- L section (ping-pong form: this wave group loads while the other one multiplies): LDS-DMA of K-step s+D, every LDS access of the step
+      if (s + D < NKT) issue(ld_c, s + D, slot_i); else issue(ld_n, s + D - NKT, slot_i);
       slot_i = slot_i + 1 == NSLOT ? 0 : slot_i + 1;
+      XACC(1);
+      // ---- every LDS operation of the step in one burst: the K-step's fragments, then the staging round trip of the FIRST
+      //      half-strip that rides on it.  LDS operations of a wave complete in order, so the MFMAs below wait (counted
+      //      lgkmcnt) for the fragments only, and the staging reads come back underneath them; measured in-kernel before this
+      //      reordering: 770 cycles per step for the fragment reads and 400 more for a separate staging round trip.
       bf16x8_t fa[4], fb[4];
       const char* sl = smem + slot_c * XSLOT;
 #pragma unroll
@@ -208,31 +243,47 @@ __device__ __forceinline__ void expand_body(const ExpArgs& p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sl + a_off + i * 1024);
       slot_c = slot_c + 1 == NSLOT ? 0 : slot_c + 1;
-      if (!(p.debug & 1)) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[CUR][j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[CUR][j][i], 0, 0, 0);
-      }
-      // ---- half-strips of the previous tile's epilogue that ride on this K-step
-      static_for<0, hs_count<NKT>(s)>([&](auto KC) {
-        constexpr int e = hs_first<NKT>(s) + decltype(KC)::value, i = e >> 1, h = e & 1;
-        if (p.debug & 2) {
-          if (!(p.debug & 4)) {
-            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0, 0, 0, 0}, out_p.o, o_vo, e * o_step, 0);
-            if (RES) { const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(out_c.r, r_vo, e * r_step, 0); rq[e] = make_uint4(t[0], t[1], t[2], t[3]); }
-          }
-          return;
-        }
+      constexpr int NH = hs_count<NKT>(s);
+      f32x4_t x0, x1;
+      auto stage = [&](auto EC) {                   // fragments of strip i -> staging (first half only), rows of half-strip e back
+        constexpr int e = decltype(EC)::value, i = e >> 1, h = e & 1;
         if (h == 0) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             *reinterpret_cast<f32x4_t*>(stg + stg_w + (((j * 4 + fgrp) ^ frow) << 4)) = acc[PRV][j][i];
         }
         const int r16 = h * 8 + rrow;
-        const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(stg + r16 * 256 + (((2 * rq8) ^ r16) << 4));
-        const f32x4_t x1 = *reinterpret_cast<const f32x4_t*>(stg + r16 * 256 + (((2 * rq8 + 1) ^ r16) << 4));
+        x0 = *reinterpret_cast<const f32x4_t*>(stg + r16 * 256 + (((2 * rq8) ^ r16) << 4));
+        x1 = *reinterpret_cast<const f32x4_t*>(stg + r16 * 256 + (((2 * rq8 + 1) ^ r16) << 4));
+      };
+      if constexpr (NH > 0) stage(std::integral_constant<int, hs_first<NKT>(s)>{});
+      // group 1 publishes its pieces of K-step s+1 here (group 0 reads them in the next section), group 0 at the end of M
+      if (PP) {
+        if (wm == 1) xwait_vm<younger_than_dma<NKT, D, OPS>(s + 1) - OPS * NH>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // fragments and staged rows are in registers: the slot may be refilled
+      }
+      XACC(2);
+#ifdef XSTAMPS
+      xs[7] += 1;
+#endif
+      if (PP) {
+        __builtin_amdgcn_s_barrier();                          // B1
+        asm volatile("" ::: "memory");
+        XACC(0);
+      }
+      // ---- M section: 16 MFMAs (at raised priority in the ping-pong form), then the arithmetic and the store of the staged half-strip
+      if (PP) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[CUR][j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[CUR][j][i], 0, 0, 0);
+      if (PP) __builtin_amdgcn_s_setprio(0);
+      XACC(3);
+      // ---- arithmetic + store of the half-strips that ride on this K-step (issued behind the MFMAs, executing beside them)
+      static_for<0, NH>([&](auto KC) {
+        constexpr int e = hs_first<NKT>(s) + decltype(KC)::value;
+        if constexpr (decltype(KC)::value > 0) stage(std::integral_constant<int, e>{});
+        XACC(4);
         float v[8];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -248,7 +299,7 @@ __device__ __forceinline__ void expand_body(const ExpArgs& p) {
             v[2 * c + 1] += __uint_as_float(pr[c] & 0xffff0000u);
           }
         }
-        if (p.relu) {
+        if (RELU) {
 #pragma unroll
           for (int c = 0; c < 8; ++c) asm("v_max_f32 %0, 0, %1" : "=v"(v[c]) : "v"(v[c]));
         }
@@ -256,13 +307,23 @@ __device__ __forceinline__ void expand_body(const ExpArgs& p) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) pk[c] = (bf16_t)v[c];
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-        if (p.debug & 4) return;
+#ifdef XSTAMPS
+        asm volatile("" :: "v"(*reinterpret_cast<const u32x4_t*>(pk)));
+        XACC(5);
+#endif
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t*>(pk), out_p.o, o_vo, e * o_step, 0);
         if (RES) {
           const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(out_c.r, r_vo, e * r_step, 0);
           rq[e] = make_uint4(t[0], t[1], t[2], t[3]);
         }
+        XACC(6);
       });
+      if (PP) {
+        if (wm == 0) xwait_vm<younger_than_dma<NKT, D, OPS>(s + 1)>();
+        __builtin_amdgcn_s_barrier();                          // B2
+        asm volatile("" ::: "memory");
+        XACC(0);
+      }
     });
     // the drained set starts the next tile from zero
 #pragma unroll
@@ -280,275 +341,36 @@ __device__ __forceinline__ void expand_body(const ExpArgs& p) {
     body(std::integral_constant<int, 0>{}, it);
     if (it + 1 <= tiles_mine) body(std::integral_constant<int, 1>{}, it + 1);
   }
+  if (PP && wm == 0) __builtin_amdgcn_s_barrier();   // (group 1 finishes its last section)
   xwait_vm<0>();
-}
-
-// =====================================================================================================
-// Variant 2: TWO workgroups per CU, one accumulator set each (<= 128 registers per lane -> four waves per SIMD).
-//
-// The double-accumulator kernel above overlaps K loop and epilogue inside one instruction stream, but with two waves per SIMD
-// every wave's step is one long dependent chain (wait - barrier - DMA issue - fragment reads - MFMAs - staging round trip -
-// arithmetic - store) and the chains of all eight waves run in lock-step: measured 1.59 ms on layer3 against 0.94 ms for
-// its epilogue alone and 0.81 ms for its K loop alone.  Here each workgroup runs the plain order (K loop of a tile, then its
-// epilogue) and the OVERLAP comes from the second workgroup on the same CU, which is in the other phase most of the time:
-// four waves per SIMD hide each other's latencies.  Same tile, ring, staging and counted-vmcnt discipline; per workgroup
-// 3 ring slots (72 KiB) + 8 KiB of escale/bias = 80 KiB; the staging strips live in the ring slot the tile's last K-step was
-// read from (free until the next tile's first barrier).
-// =====================================================================================================
-#ifndef XP
-#define XP 2
+#ifdef XSTAMPS
+  if (blockIdx.x < 256 && lane == 0) {
+    unsigned long long* o = g_xstamps + (blockIdx.x * 8 + wave) * 8;
+    for (int k = 0; k < 8; ++k) o[k] = xs[k];
+  }
 #endif
-struct XSeq { int n; int kind[160]; int idx[160]; };   // kind: 0 LDS-DMA piece (idx = K-step it serves), 1 residual load (idx = half-strip), 2 store,
-                                                        //       10 wait-for-DMA marker (idx = K-step), 11 wait-for-residual marker (idx = half-strip)
-template <int NKT, int D, int P, bool RES> constexpr XSeq x_sequence() {
-  XSeq q{};
-  auto add = [&](int k, int i) { q.kind[q.n] = k; q.idx[q.n] = i; ++q.n; };
-  for (int s = 0; s < NKT; ++s) {
-    add(10, s);
-    for (int k = 0; k < 3; ++k) add(0, (s + D) % NKT);
-  }
-  if (RES) for (int e = 0; e < P; ++e) add(1, e);       // the first P residual chunks: requested when the K loop ends (no register
-  for (int e = 0; e < 8; ++e) {                          // is held across the K loop: the kernel must fit 128 per lane)
-    if (RES) add(11, e);
-    add(2, e);
-    if (RES && e + P < 8) add(1, e + P);
-  }
-  return q;
-}
-// operations issued after the most recent (kind, idx) operation and before marker (mkind, midx), in the periodic stream
-template <int NKT, int D, int P, bool RES> constexpr int x_younger(int kind, int idx, int mkind, int midx) {
-  const XSeq q = x_sequence<NKT, D, P, RES>();
-  int m = -1;
-  for (int i = 0; i < q.n; ++i) if (q.kind[i] == mkind && q.idx[i] == midx) m = i;
-  int cnt = 0;
-  for (int back = 1; back <= q.n; ++back) {
-    const int i = ((m - back) % q.n + q.n) % q.n;
-    if (q.kind[i] == kind && q.idx[i] == idx) return cnt;
-    if (q.kind[i] < 10) ++cnt;
-  }
-  return 0;
 }
 
-template <int NKT, bool RES>
-__device__ __forceinline__ void expand2_body(const ExpArgs& p) {
-  constexpr int NSLOT = 3, D = 2, P = XP;
-  static_assert(D <= NKT, "the loader runs at most one tile ahead");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* const vec = reinterpret_cast<float*>(smem + NSLOT * XSLOT);   // [2][N]: escale, bias
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int gn = p.N >> 8;
-  const int nblk = (p.M + 127) >> 7;
-  const int G = gridDim.x;
-  int vb = blockIdx.x;
-  {
-    const int xcd = vb & 7, q = G >> 3, r = G & 7;
-    vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-  }
-  const int my_blocks = vb < nblk ? (nblk - vb + G - 1) / G : 0;
-  const int tiles_mine = my_blocks * gn;
-  if (tiles_mine == 0) return;
-
-  for (int i = threadIdx.x; i < p.N; i += 512) {
-    vec[i] = p.escale ? p.escale[i] : 1.f;
-    vec[p.N + i] = p.bias ? p.bias[i] : 0.f;
-  }
-
-  // lane-constant addressing of the loader and of the fragment reads (recomputed from a fresh lane id at the top of every
-  // tile, see `tile_consts`: nothing but the accumulators is live across both the K loop and the epilogue)
-  int a_row, a_vo_ok, w_vo0, w_vo1, a_off, b_off;
-  auto tile_consts = [&]() {
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    const int prow = l >> 2;
-    const int ec = ((l & 3) ^ ((l >> 5) << 1)) * 8;
-    a_row = wave * 16 + prow;
-    a_vo_ok = (int)((a_row * p.lda + ec) * 2);
-    w_vo0 = (int)(((wave * 16 + prow) * p.ldw + ec) * 2);
-    w_vo1 = (int)((((wave + 8) * 16 + prow) * p.ldw + ec) * 2);
-    const int fsw = ((l >> 4) ^ ((l & 8) >> 2)) << 4;
-    a_off = (wm * 64 + (l & 15)) * 64 + fsw;
-    b_off = 8192 + (wn * 64 + (l & 15)) * 64 + fsw;
-  };
-  tile_consts();
-  char* const a_dst = smem + wave * 1024;
-  char* const w_dst0 = smem + 8192 + wave * 1024;
-  char* const w_dst1 = smem + 8192 + (wave + 8) * 1024;
-
-  struct Desc { __amdgpu_buffer_rsrc_t a, w; int a_vo; };
-  auto make_desc = [&](int blk, int tn, bool valid) {
-    Desc d;
-    const long m0 = (long)blk * 128;
-    d.a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + m0 * p.lda), 0, valid ? XNREC : 0, 0x00020000);
-    d.w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long)tn * 256 * p.ldw), 0, valid ? XNREC : 0, 0x00020000);
-    d.a_vo = (m0 + a_row < p.M) ? a_vo_ok : XOOB;
-    return d;
-  };
-  auto issue = [&](const Desc& d, int kstep, int slot) {
-    const int so = kstep * 64;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(d.a, (__attribute__((address_space(3))) void*)(a_dst + slot * XSLOT), 16, d.a_vo, so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(d.w, (__attribute__((address_space(3))) void*)(w_dst0 + slot * XSLOT), 16, w_vo0, so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(d.w, (__attribute__((address_space(3))) void*)(w_dst1 + slot * XSLOT), 16, w_vo1, so, 0, 0);
-  };
-
-  const int o_step = (int)(8 * p.ldc * 2), r_step = (int)(8 * p.ldres * 2);
-  struct OutDesc { __amdgpu_buffer_rsrc_t o, r; int n0; };
-  auto make_out = [&](int blk, int tn) {
-    OutDesc d;
-    const long m0 = (long)blk * 128;
-    const long rows = (long)p.M - m0 < 128 ? (long)p.M - m0 : 128;
-    const int n0 = tn * 256;
-    d.o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + m0 * p.ldc + n0), 0, (int)(((rows - 1) * p.ldc + 256) * 2), 0x00020000);
-    d.r = __builtin_amdgcn_make_buffer_rsrc((void*)((RES ? p.res : p.out) + m0 * p.ldres + n0), 0,
-                                            RES ? (int)(((rows - 1) * p.ldres + 256) * 2) : 0, 0x00020000);
-    d.n0 = n0;
-    return d;
-  };
-
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-
-  int blk_c = vb, tn_c = 0;
-  Desc ld_c = make_desc(blk_c, tn_c, true);
-#pragma unroll
-  for (int s = 0; s < D; ++s) issue(ld_c, s, s);
-  xwait_vm<0>();
-  __syncthreads();
-  int slot_c = 0, slot_i = D % NSLOT;
-
-  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  for (int it = 0; it < tiles_mine; ++it) {
-    int blk_n = blk_c, tn_n = tn_c + 1;
-    if (tn_n == gn) { tn_n = 0; blk_n += G; }
-    tile_consts();
-    ld_c.a_vo = ((long)blk_c * 128 + a_row < p.M) ? a_vo_ok : XOOB;
-    const Desc ld_n = make_desc(blk_n, tn_n, it + 1 < tiles_mine);
-    const OutDesc od = make_out(blk_c, tn_c);
-    int stg_slot = 0;
-    // ---------------- K loop ----------------
-    static_for<0, NKT>([&](auto SC) {
-      constexpr int s = decltype(SC)::value;
-      xwait_vm<x_younger<NKT, D, P, RES>(0, s, 10, s)>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (s + D < NKT) issue(ld_c, s + D, slot_i); else issue(ld_n, s + D - NKT, slot_i);
-      slot_i = slot_i + 1 == NSLOT ? 0 : slot_i + 1;
-      const char* sl = smem + slot_c * XSLOT;
-      bf16x8_t fb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(sl + b_off + j * 1024);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(sl + a_off + i * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[j][i], 0, 0, 0);
-      }
-      if (s == NKT - 1) stg_slot = slot_c;
-      slot_c = slot_c + 1 == NSLOT ? 0 : slot_c + 1;
-    });
-    // ---------------- epilogue ----------------
-    // lane-constant values are recomputed here from a fresh lane id: kept live across the K loop they would not fit 128 registers
-    int el;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
-    const int rrow = el >> 3, rq8 = el & 7, frow = el & 15, fgrp = el >> 4;
-    const int o_vo = (int)((((wm * 64 + rrow) * p.ldc) + wn * 64 + rq8 * 8) * 2);
-    const int r_vo = (int)((((wm * 64 + rrow) * p.ldres) + wn * 64 + rq8 * 8) * 2);
-    u32x4_t rq[P];
-#pragma unroll
-    for (int e = 0; e < P; ++e) rq[e] = RES ? __builtin_amdgcn_raw_buffer_load_b128(od.r, r_vo, e * r_step, 0) : u32x4_t{0, 0, 0, 0};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                  // every wave has read the last K-step's fragments: its slot becomes the staging area
-    asm volatile("" ::: "memory");
-    char* const stg = smem + stg_slot * XSLOT + wave * 2048;      // per wave: 8 rows x 64 columns fp32, chunk c of row r at c ^ r
-    const float* const ev = vec + od.n0 + wn * 64 + rq8 * 8;
-    static_for<0, 8>([&](auto EC) {
-      constexpr int e = decltype(EC)::value, i = e >> 1, h = e & 1;
-      if ((frow >> 3) == h) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4_t*>(stg + (frow & 7) * 256 + (((j * 4 + fgrp) ^ (frow & 7)) << 4)) = acc[j][i];
-      }
-      if (RES) xwait_vm<x_younger<NKT, D, P, RES>(1, e, 11, e)>();
-      // four columns at a time (x, escale, bias live only for their half: the kernel must fit 128 registers per lane)
-      u32x4_t ow;
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const f32x4_t x = *reinterpret_cast<const f32x4_t*>(stg + rrow * 256 + (((2 * rq8 + hh) ^ rrow) << 4));
-        const f32x4_t es = *reinterpret_cast<const f32x4_t*>(ev + 4 * hh);
-        const f32x4_t bs = *reinterpret_cast<const f32x4_t*>(ev + p.N + 4 * hh);
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaf(x[c], es[c], bs[c]);
-        if (RES) {
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            v[2 * c] += __uint_as_float(rq[e % P][2 * hh + c] << 16);
-            v[2 * c + 1] += __uint_as_float(rq[e % P][2 * hh + c] & 0xffff0000u);
-          }
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) asm("v_max_f32 %0, 0, %1" : "=v"(v[c]) : "v"(v[c]));
-        }
-        bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        ow[2 * hh] = reinterpret_cast<const unsigned*>(pk)[0];
-        ow[2 * hh + 1] = reinterpret_cast<const unsigned*>(pk)[1];
-        asm volatile("" : "+v"(ow));          // keep the two halves apart (the scheduler would hoist all six LDS reads)
-      }
-      __builtin_amdgcn_raw_buffer_store_b128(ow, od.o, o_vo, e * o_step, 0);
-      if (RES && e + P < 8) rq[e % P] = __builtin_amdgcn_raw_buffer_load_b128(od.r, r_vo, (e + P) * r_step, 0);
-    });
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    blk_c = blk_n; tn_c = tn_n;
-    ld_c = ld_n;
-  }
-  xwait_vm<0>();
-}
-
-template <int NKT, bool RES>
-__global__ __launch_bounds__(512, 4) void conv1x1_expand2_kernel(const ExpArgs p) { expand2_body<NKT, RES>(p); }
+// Tried and removed: a variant with TWO workgroups per CU (one accumulator set, <= 128 registers, K loop and epilogue in plain
+// order, the overlap left to the second workgroup).  End to end it was 0.7 % slower than this kernel (the residual prefetch
+// shrank to two chunks per wave to stay under 128 registers) and its race screen was not clean (tools/race_expand.py).
 
 // (thin kernel around a __device__ body: with the generic lambdas inside the __global__ function itself hipcc's HOST pass
 //  silently drops the kernel's launch stub and the library no longer links)
-template <int NKT, int NSLOT, bool RES>
-__global__ __launch_bounds__(512, 2) void conv1x1_expand_kernel(const ExpArgs p) { expand_body<NKT, NSLOT, RES>(p); }
+template <int NKT, int NSLOT, bool RES, bool RELU>
+__global__ __launch_bounds__(512, 2) void conv1x1_expand_kernel(const ExpArgs p) { expand_body<NKT, NSLOT, RES, RELU, NKT == 4>(p); }
 
 inline bool expand_enabled() {
   static const bool off = [] { const char* e = getenv("SR_NO_EXPAND"); return e && e[0] == '1'; }();
   return !off;
 }
 
-template <int NKT, int NSLOT, bool RES> struct XTag {};
-template <int NKT, bool RES> struct XTag2 {};
-
-inline int expand_variant() {     // SR_EXPAND_VARIANT: 1 = one workgroup per CU, two accumulator sets; 2 (default) = two workgroups per CU
-  static const int v = [] { const char* e = getenv("SR_EXPAND_VARIANT"); return e ? atoi(e) : 2; }();
-  return v;
-}
-
-template <int NKT>
-int launch_expand2(const ExpArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)3 * XSLOT + (size_t)a.N * 8;
-  static const bool half = [] { const char* e = getenv("SR_GEMM_HALF"); return e && e[0] == '1'; }();
-  const int nblk = (a.M + 127) / 128, cap = (half ? 1 : 2) * sr_num_cus();
-  const unsigned grid = (unsigned)(nblk < cap ? nblk : cap);
-  if (a.res) {
-    if (!sr_set_dynamic_lds_tagged<XTag2<NKT, true>>(reinterpret_cast<const void*>(&conv1x1_expand2_kernel<NKT, true>), (int)lds)) return SR_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv1x1_expand2_kernel<NKT, true>), dim3(grid), dim3(512), lds, st, a);
-  } else {
-    if (!sr_set_dynamic_lds_tagged<XTag2<NKT, false>>(reinterpret_cast<const void*>(&conv1x1_expand2_kernel<NKT, false>), (int)lds)) return SR_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv1x1_expand2_kernel<NKT, false>), dim3(grid), dim3(512), lds, st, a);
-  }
+template <int NKT, int NSLOT, bool RES, bool RELU> struct XTag {};
+template <int NKT, int NSLOT, bool RES, bool RELU>
+int launch_expand_v(const ExpArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+  if (!sr_set_dynamic_lds_tagged<XTag<NKT, NSLOT, RES, RELU>>(reinterpret_cast<const void*>(&conv1x1_expand_kernel<NKT, NSLOT, RES, RELU>), (int)lds))
+    return SR_ERR_LAUNCH;
+  hipLaunchKernelGGL((conv1x1_expand_kernel<NKT, NSLOT, RES, RELU>), dim3(grid), dim3(512), lds, st, a);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -558,18 +380,18 @@ int launch_expand(const ExpArgs& a, hipStream_t st) {
   const size_t lds = (size_t)NSLOT * XSLOT + 8 * XSTG + (size_t)a.N * 8;
   const int nblk = (a.M + 127) / 128, cus = sr_num_cus();
   const unsigned grid = (unsigned)(nblk < cus ? nblk : cus);
-  if (a.res) {
-    if (!sr_set_dynamic_lds_tagged<XTag<NKT, NSLOT, true>>(reinterpret_cast<const void*>(&conv1x1_expand_kernel<NKT, NSLOT, true>), (int)lds)) return SR_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv1x1_expand_kernel<NKT, NSLOT, true>), dim3(grid), dim3(512), lds, st, a);
-  } else {
-    if (!sr_set_dynamic_lds_tagged<XTag<NKT, NSLOT, false>>(reinterpret_cast<const void*>(&conv1x1_expand_kernel<NKT, NSLOT, false>), (int)lds)) return SR_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv1x1_expand_kernel<NKT, NSLOT, false>), dim3(grid), dim3(512), lds, st, a);
-  }
-  SR_CHECK_LAUNCH();
-  return SR_OK;
+  if (a.res) return a.relu ? launch_expand_v<NKT, NSLOT, true, true>(a, grid, lds, st) : launch_expand_v<NKT, NSLOT, true, false>(a, grid, lds, st);
+  return a.relu ? launch_expand_v<NKT, NSLOT, false, true>(a, grid, lds, st) : launch_expand_v<NKT, NSLOT, false, false>(a, grid, lds, st);
 }
 
 }  // namespace
+
+#ifdef XSTAMPS
+extern "C" int srx_expand_stamps(unsigned long long* host_out) {
+  if (hipDeviceSynchronize() != hipSuccess) return SR_ERR_LAUNCH;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_xstamps), sizeof(unsigned long long) * 256 * 8 * 8) == hipSuccess ? SR_OK : SR_ERR_LAUNCH;
+}
+#endif
 
 // Internal (not part of include/srhip.h): sr_conv2d hands over the launches this kernel serves.  Returns SR_ERR_UNSUPPORTED
 // when the shape is not one of them (the caller then uses the generic kernel).
@@ -586,16 +408,7 @@ int srx_conv1x1_expand(const sr_conv_args* a, long M, void* stream) {
   x.out = (bf16_t*)a->y; x.ldc = a->Cout;
   x.escale = a->escale; x.bias = a->bias;
   x.M = (int)M; x.N = a->Cout; x.K = a->Cin; x.relu = a->act == SR_ACT_RELU;
-  static const int dbg = [] { const char* e = getenv("SR_EXPAND_DEBUG"); return e ? atoi(e) : 0; }();
-  x.debug = dbg;
   hipStream_t st = (hipStream_t)stream;
-  if (expand_variant() == 2) {
-    switch (a->Cin) {
-      case 64: return launch_expand2<2>(x, st);
-      case 128: return launch_expand2<4>(x, st);
-      default: return launch_expand2<8>(x, st);
-    }
-  }
   switch (a->Cin) {
     case 64: return launch_expand<2, 3>(x, st);
     case 128: return launch_expand<4, 5>(x, st);

@@ -1,15 +1,13 @@
 set -o pipefail
 mkdir -p gpurun_out
-run() { tag=$1; shift
-  env "$@" timeout -k 10 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/r2_bench_$tag.json 2> gpurun_out/r2_bench_$tag.err; rc=$?
-  echo "$tag rc=$rc $(python3 -c "
+timeout -k 10 300 python tools/race_expand.py 20 2>&1 | grep -v amdgpu.ids; rc=$?
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 120 python tools/bench_expand.py 3 2 1 2>&1 | grep layer
+timeout -k 10 1000 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/r2_tests4.log 2>&1; rc=$?
+echo "pytest rc=$rc"; tail -8 gpurun_out/r2_tests4.log
+[ $rc -lt 124 ] || exit $rc
+for ov in 0 1; do
+SR_OVERLAP=$ov timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/r2_bench_ov$ov.json 2> gpurun_out/r2_bench_ov$ov.err; echo "ov=$ov $(python3 -c "
 import json
-d=json.load(open('gpurun_out/r2_bench_$tag.json')); print(d['value'], d['ms_per_step'])" 2>/dev/null)"
-  [ $rc -lt 124 ] || exit $rc; }
-run base SR_OVERLAP=0
-run ov SR_OVERLAP=1
-run ov_half SR_OVERLAP=1 SR_GEMM_HALF=1 SR_GEMM_NARROW=2
-run half_noov SR_OVERLAP=0 SR_GEMM_HALF=1 SR_GEMM_NARROW=2
-run ov_half_p2 SR_OVERLAP=1 SR_GEMM_HALF=1 SR_GEMM_NARROW=2 SR_PHASE_UNITS=2
-run ov_half_p3 SR_OVERLAP=1 SR_GEMM_HALF=1 SR_GEMM_NARROW=2 SR_PHASE_UNITS=3
-run ov_p3 SR_OVERLAP=1 SR_PHASE_UNITS=3
+d=json.load(open('gpurun_out/r2_bench_ov$ov.json')); print(d['value'], d['ms_per_step'])")"
+done
