@@ -194,8 +194,9 @@ __device__ __forceinline__ void expand_body(const ExpArgs& p) {
   //   read-after-DMA : group 0 reads K-step s+1 in the section after its M(s), group 1 one section later; every wave has waited
   //                    for its own pieces of K-step s+1 before the barrier in front of group 0's read (group 0 at the end of
   //                    M(s), group 1 at the end of its L(s), the same time slot).
-  // PP is chosen per shape by measurement (layer2's K = 128: 2054 us against 2470 in lock-step; K = 256 and K = 64 lose: with
-  // four waves in every section the LDS burst halves but the LDS-DMA issue backs up behind the other group's stores).
+  // PP (SR_EXPAND_PP) is off by default: interleaved A/B runs at batch 6144 (3 x 8 launches each) gave, lock-step / ping-pong /
+  // generic 256x256 kernel: K=256 1486 / 1585 / 1686 us, K=128 2063 / 2075 / 2426 us, K=64 4160 / 4250 / 4214 us -- with four
+  // waves in every section the LDS burst halves, but the LDS-DMA issue backs up behind the other group's stores.
   if (PP && wm == 1) __builtin_amdgcn_s_barrier();
 
   int slot_c = 0, slot_i = D % NSLOT;       // ring slot read by the next K-step / filled by the next issue
@@ -357,22 +358,34 @@ __device__ __forceinline__ void expand_body(const ExpArgs& p) {
 
 // (thin kernel around a __device__ body: with the generic lambdas inside the __global__ function itself hipcc's HOST pass
 //  silently drops the kernel's launch stub and the library no longer links)
-template <int NKT, int NSLOT, bool RES, bool RELU>
-__global__ __launch_bounds__(512, 2) void conv1x1_expand_kernel(const ExpArgs p) { expand_body<NKT, NSLOT, RES, RELU, NKT == 4>(p); }
+template <int NKT, int NSLOT, bool RES, bool RELU, bool PP>
+__global__ __launch_bounds__(512, 2) void conv1x1_expand_kernel(const ExpArgs p) { expand_body<NKT, NSLOT, RES, RELU, PP>(p); }
 
 inline bool expand_enabled() {
   static const bool off = [] { const char* e = getenv("SR_NO_EXPAND"); return e && e[0] == '1'; }();
   return !off;
 }
 
-template <int NKT, int NSLOT, bool RES, bool RELU> struct XTag {};
-template <int NKT, int NSLOT, bool RES, bool RELU>
-int launch_expand_v(const ExpArgs& a, unsigned grid, size_t lds, hipStream_t st) {
-  if (!sr_set_dynamic_lds_tagged<XTag<NKT, NSLOT, RES, RELU>>(reinterpret_cast<const void*>(&conv1x1_expand_kernel<NKT, NSLOT, RES, RELU>), (int)lds))
+template <int NKT, int NSLOT, bool RES, bool RELU, bool PP> struct XTag {};
+
+// which K variants run the half-step ping-pong form: bit 0 K=64, bit 1 K=128, bit 2 K=256 (SR_EXPAND_PP overrides, for A/B runs)
+inline int expand_pp_mask() {
+  static const int m = [] { const char* e = getenv("SR_EXPAND_PP"); return e ? atoi(e) : 0; }();
+  return m;
+}
+template <int NKT, int NSLOT, bool RES, bool RELU, bool PP>
+int launch_expand_p(const ExpArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+  if (!sr_set_dynamic_lds_tagged<XTag<NKT, NSLOT, RES, RELU, PP>>(reinterpret_cast<const void*>(&conv1x1_expand_kernel<NKT, NSLOT, RES, RELU, PP>), (int)lds))
     return SR_ERR_LAUNCH;
-  hipLaunchKernelGGL((conv1x1_expand_kernel<NKT, NSLOT, RES, RELU>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_expand_kernel<NKT, NSLOT, RES, RELU, PP>), dim3(grid), dim3(512), lds, st, a);
   SR_CHECK_LAUNCH();
   return SR_OK;
+}
+template <int NKT, int NSLOT, bool RES, bool RELU>
+int launch_expand_v(const ExpArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+  const int bit = NKT == 2 ? 1 : (NKT == 4 ? 2 : 4);
+  return (expand_pp_mask() & bit) ? launch_expand_p<NKT, NSLOT, RES, RELU, true>(a, grid, lds, st)
+                                  : launch_expand_p<NKT, NSLOT, RES, RELU, false>(a, grid, lds, st);
 }
 
 template <int NKT, int NSLOT>

@@ -642,9 +642,8 @@ class FCGGNN(nn.Module):
         self._shadow = _Shadow()
         self._drop_counter = 0
         self.drop_seed_base = 0x5eed
-        # noun backbone on a second stream (see forward): True / False / None = automatic (per-GPU batches up to 4096: worth 8 %
-        # at 768, 4 % at 1536 and 3072; at 6144 it is worth 2 % and makes every kernel's duration in a profile depend on its
-        # neighbour's)
+        # noun backbone on a second stream (see forward): True / False / None = on (worth 8 % at per-GPU batch 768, 4 % at 1536
+        # and 3072, 3 % at 6144; profiling legs switch it off so that a kernel's duration does not depend on its neighbour's)
         env = os.environ.get("SR_OVERLAP")
         self.overlap_backbones = None if env is None else env not in ("0", "")
         self._side_streams = {}
@@ -694,7 +693,7 @@ class FCGGNN(nn.Module):
 
     def forward(self, img, gt_verb):                                                    # model.py:172-180
         batch_size = img.size(0)
-        overlap = self.overlap_backbones if self.overlap_backbones is not None else batch_size <= 4096
+        overlap = self.overlap_backbones if self.overlap_backbones is not None else True
         if self.share_identical_backbones and self.training and img.is_cuda and self.convnet_verbs.weights_equal(self.convnet_nouns):
             # Both backbones still hold the SAME frozen weights (what the reference's two `pretrained=True` loads give) and
             # train-mode BatchNorm ignores the running statistics: their features are identical, so ONE pass serves the verb

@@ -89,9 +89,14 @@ def test_config3_resnet152_bf16_batch6144_slicing_oracle_and_train_invariants():
     # A 32-image launch runs other kernels than the 6144-image one (narrow tiles; the expansion-conv kernel of csrc/expand.hip,
     # which rounds to bf16 once instead of twice, only serves launches of >= 32 768 rows), so the two differ by bf16 rounding
     # noise amplified through 152 layers -- the same bound as against the fp32 oracle below, not bit equality.
+    # (pred_nouns is conditioned on argmax(pred_verb): only images whose predicted verb agrees between the two runs are compared)
     for lo, part in parts.items():
-        for f, p in zip(full, part):
-            assert float((f[lo:lo + 32].float() - p.float()).abs().max()) <= 0.15, lo
+        same = (full[0][lo:lo + 32].float().argmax(1) == part[0].float().argmax(1))
+        for k, (f, p) in enumerate(zip(full, part)):
+            d = (f[lo:lo + 32].float() - p.float()).abs().flatten(1).max(1)[0]
+            if k == 1:
+                d = d[same]
+            assert d.numel() == 0 or float(d.max()) <= 0.15, (lo, k, float(d.max()))
     # bf16 storage through 152 layers against the fp32 oracle: no 1e-3 claim here (that is config 2, fp32 storage).  Rounding
     # every activation to 8 significant bits gives a random walk of ~0.4 % per layer: a few percent on the pooled features,
     # and the same ABSOLUTE error on logits (|h| and |W| are O(1)); measured 4-5 % / 0.06, asserted at twice that.
