@@ -121,7 +121,11 @@ def spawn_ranks(args, argv):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     log("spawning %d ranks: %s" % (args.gpus, " ".join(cmd)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.run(cmd, env=env).returncode
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:                      # ONE JSON line on stdout: anything else the ranks print (backend banners) goes to stderr
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return p.wait()
 
 
 def profile_step(step_fn, ops, torch):
@@ -251,7 +255,7 @@ def main():
                    "final_loss": round(final_loss, 4)},
     }
 
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:                  # (every rank runs the profiled step -- it contains the collectives -- rank 0 reports it)
         # One extra training step, every libsrhip launch bracketed by HIP events on its launch stream (single stream: the
         # two-stream overlap of small batches is switched off so that a launch's duration is its own).
         # Headline = the dominant kernel family conv_igemm_* (backbone implicit-GEMM convolutions) on the MFMA roofline,
@@ -264,6 +268,7 @@ def main():
         net.overlap_backbones = False
         agg = profile_step(step, ops, torch)
         net.overlap_backbones = keep
+    if rank == 0 and not args.no_roofline:
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
 
         def entry(tags, bound, kernel):

@@ -317,9 +317,9 @@ def node_init_bwd(dnode, feat, role_emb, verb_emb, verbs, role_table, d_role_emb
     NR = role_emb.shape[0] - 1
     if tuple(d_role_emb.shape) != (NR + 1, D) or tuple(d_verb_emb.shape) != (V, D) or verb_emb.shape[0] != V:
         raise L.SrError("node_init_bwd: gradient / table shapes do not match")
-    order = torch.argsort(verbs, stable=True).to(torch.int32)
-    seg = torch.zeros(V + 1, dtype=torch.int32, device=verbs.device)
-    seg[1:] = torch.cumsum(torch.bincount(verbs, minlength=V), 0)
+    sorted_verbs, order = torch.sort(verbs, stable=True)            # (no host synchronisation: bincount would need one)
+    seg = torch.searchsorted(sorted_verbs, torch.arange(V + 1, device=verbs.device, dtype=verbs.dtype)).to(torch.int32)
+    order = order.to(torch.int32)
     inv_ptr, inv_slot = _role_inverted_index(role_table, NR)
     scratch = torch.empty((V * R, D), device=feat.device, dtype=torch.float32)
     check(lib().sr_node_init_bwd(dnode.data_ptr(), feat.data_ptr(), role_emb.data_ptr(), verb_emb.data_ptr(), order.data_ptr(),

@@ -53,8 +53,8 @@ wrap("conv2d", conv_key)
 wrap("bn_apply", apply_key)
 wrap("gram", lambda x: ("gram C=%4d M=%d" % (x.shape[1], x.shape[0]), 2.0 * x.shape[0] * x.shape[1] ** 2, 2.0 * x.numel()))
 wrap("bn_apply_gram", lambda x, sc, sh: ("bn_apply+gram C=%4d M=%d" % (x.shape[1], x.shape[0]), 2.0 * x.shape[0] * x.shape[1] ** 2, 4.0 * x.numel()))
-wrap("bn_finalize_gram", lambda part, w, *a: ("bn_finalize_gram C=%4d N=%4d" % (w.shape[1], w.shape[0]), 0.0, 4.0 * part.numel()))
-wrap("bn_finalize", lambda st, *a: ("bn_finalize C=%4d tiles=%d" % (st.shape[2], st.shape[0]), 0.0, 4.0 * st.numel()))
+wrap("bn_finalize_gram", lambda part, w, *a, **k: ("bn_finalize_gram C=%4d N=%4d" % (w.shape[1], w.shape[0]), 0.0, 4.0 * part.numel()))
+wrap("bn_finalize", lambda st, *a, **k: ("bn_finalize C=%4d tiles=%d" % (st.shape[2], st.shape[0]), 0.0, 4.0 * st.numel()))
 wrap("maxpool3x3s2", lambda x, *a: ("maxpool", 0.0, 2.0 * x.numel() * 1.25))
 wrap("avgpool", lambda x: ("avgpool", 0.0, 2.0 * x.numel()))
 
