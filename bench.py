@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0                    # HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 achievable)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_FP8_TFLOPS = 5000.0           # dense fp8 (block-scaled MFMA, K = 128)
 RESNET_GFLOP = {18: 3.627, 50: 8.174, 152: 23.023}     # per image per pass at 224x224
 
 
@@ -156,6 +157,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fp8", action="store_true",
+                    help="BASELINE config 5: the bottlenecks' 3x3 convolutions on the 2x-rate fp8 (e4m3) MFMA, everything else bf16 "
+                         "(quote it with --T 8 --global-batch 8192).  Not the headline configuration.")
     ap.add_argument("--shared-backbone", action="store_true",
                     help="both backbones start from the SAME weights (what the reference's two pretrained=True loads give, "
                          "model.py:16,100-101): FCGGNN then runs one train-mode pass for both.  Not the headline configuration.")
@@ -184,7 +188,7 @@ def main():
     enc = imsitu_encoder.synthetic()                              # V=504, 190 roles, L=2001, R=6
     torch.manual_seed(1238)                                       # identical replicas on every rank
     D = 2048 if args.backbone >= 50 else 512
-    net = FCGGNN(enc, D, steps=args.T, backbone=args.backbone, dtype=dtype)
+    net = FCGGNN(enc, D, steps=args.T, backbone=args.backbone, dtype=dtype, fp8=args.fp8)
     if args.shared_backbone:
         net.convnet_nouns.load_state_dict(net.convnet_verbs.state_dict())
     net = net.to(dev)
@@ -246,7 +250,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype + ("+fp8(e4m3) 3x3 convolutions" if args.fp8 else ""), "data": "synthetic",
         "config": {"workload": "ResNet-%d backbone (x2, frozen, train-mode BN) + 6-role GGNN T=%d + verb/noun classifiers, "
                                "full training step, global batch %d, %dx%d synthetic images, imSitu-sized vocabulary "
                                "(504 verbs / 190 roles / 2001 labels)" % (args.backbone, args.T, args.global_batch, args.res, args.res),
@@ -280,14 +284,15 @@ def main():
             bsum = sum(agg[t][3] for t in tags if t in agg)
             e = {"kernel": kernel, "launches_per_step": n, "avg_launch_ms": round(1e3 * tsum / n, 4), "ms_per_step": round(1e3 * tsum, 2)}
             if bound == "mfma":
-                e.update(bound="mfma", achieved=round(fsum / tsum / 1e12, 2), peak=peak, unit="TFLOP/s", frac=round(fsum / tsum / 1e12 / peak, 4),
+                pk = PEAK_FP8_TFLOPS if tags == ["conv3x3_fp8"] else peak
+                e.update(bound="mfma", achieved=round(fsum / tsum / 1e12, 2), peak=pk, unit="TFLOP/s", frac=round(fsum / tsum / 1e12 / pk, 4),
                          alg_gflop_per_launch=round(fsum / n / 1e9, 3))
             else:
                 e.update(bound="hbm", achieved=round(bsum / tsum / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(bsum / tsum / 1e9 / PEAK_HBM_GBS, 4),
                          alg_bytes_per_launch=round(bsum / n))
             return e
 
-        conv_tags = ["conv1x1", "conv3x3", "conv7x7"]
+        conv_tags = ["conv1x1", "conv3x3", "conv7x7", "conv3x3_fp8"]
         head = entry(conv_tags, "mfma", "conv_igemm_* (backbone implicit-GEMM convolutions, both passes, incl. statistics-only launches)")
         hbm_view = entry(conv_tags, "hbm", "conv_igemm_*")
         # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately on this exact
@@ -300,7 +305,8 @@ def main():
                 traffic = round(t["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
-        by = [entry(["conv3x3"], "mfma", "conv_igemm_* 3x3"), entry(["conv1x1"], "hbm", "conv_igemm_* 1x1 (reduce / expansion+residual / downsample)"),
+        by = [entry(["conv3x3"], "mfma", "conv_igemm_* 3x3"),
+              entry(["conv3x3_fp8"], "mfma", "conv3x3_fp8_kernel (e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4; peak = dense fp8)"), entry(["conv1x1"], "hbm", "conv_igemm_* 1x1 (reduce / expansion+residual / downsample)"),
               entry(["conv7x7"], "mfma", "conv_igemm_* 7x7 stem"),
               entry(["gram"], "hbm", "gram_kernel (Gram-matrix statistics of the expansion convs, fused with the preceding BN-apply)"),
               entry(["bn_apply"], "hbm", "bn_apply_kernel"), entry(["maxpool"], "hbm", "maxpool_kernel"),

@@ -152,6 +152,21 @@ int sr_bn_finalize_gram(const float* partials, int64_t npartials, int C, const v
                         float* running_mean2, float* running_var2, float momentum2 /* twin BatchNorm, as sr_bn_finalize */,
                         void* stream);
 
+/* ---- FP8 (OCP e4m3) path of the matrix-bound 3x3 convolutions (BASELINE config 5; the reference's reduced-precision route is
+ * autocast, model.py:33,58,114,157,171).  e4m3 activations x e4m3 weights on v_mfma_scale_f32_16x16x128_f8f6f4 (2x the bf16
+ * MFMA rate), fp32 accumulation; everything around the 3x3 stays bf16.
+ *   sr_quantize_fp8: out[i] = e4m3( f(x[i]) * act_scale ), f = [relu](x*scale[c] + shift[c]) when scale/shift are given (the
+ *     BatchNorm-apply in front of the conv writes its fp8 input directly), identity otherwise; x bf16 or fp32 [rows, C], C % 8 == 0.
+ *   sr_conv3x3_fp8: y[b,ho,wo,co] = dq[co] * sum x[b, ho*s-1+r, wo*s-1+q, c] * w[co,r,q,c]  (pad 1, stride 1 or 2), x and w e4m3,
+ *     y bf16, dq = 1 / (act_scale * weight_scale[co]) fp32; Cin in {128,256,512}, Cout % 128 == 0.  stats (optional): partial
+ *     column sums / sums of squares of the dequantised fp32 values, rows = sr_conv3x3_fp8_stats_rows(M, Cout), same layout and
+ *     meaning as sr_gemm_args.stats (sr_bn_finalize consumes them). */
+int sr_quantize_fp8(const void* x, const float* scale, const float* shift, void* out, int64_t rows, int C, int relu, float act_scale,
+                    int dtype, void* stream);
+int sr_conv3x3_fp8_stats_rows(int M, int N);
+int sr_conv3x3_fp8(const void* x, const void* w, const float* dq, void* y, float* stats, int B, int H, int W, int Cin, int Cout,
+                   int stride, void* stream);
+
 /* y = [relu]( x*scale[c] + shift[c] (+ res) ), rows x C, in place allowed. */
 int sr_bn_apply(const void* x, const float* scale, const float* shift, const void* res, void* y,
                 int64_t rows, int C, int relu, int dtype, void* stream);

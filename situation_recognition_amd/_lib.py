@@ -57,6 +57,9 @@ SIGNATURES = {
     "sr_gram": [_P, _L, _I, _L, _I, _P, _L, _P],
     "sr_bn_apply_gram": [_P, _L, _I, _L, _I, _P, _P, _P, _L, _P],
     "sr_bn_finalize_gram": [_P, _L, _I, _P, _L, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _P, _P, _F, _P],
+    "sr_quantize_fp8": [_P, _P, _P, _P, _L, _I, _I, _F, _I, _P],
+    "sr_conv3x3_fp8_stats_rows": [_I, _I],
+    "sr_conv3x3_fp8": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sr_bn_apply": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "sr_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P],
     "sr_avgpool": [_P, _P, _I, _I, _I, _I, _P],

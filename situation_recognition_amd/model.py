@@ -152,6 +152,42 @@ class _ConvBN:
             self._cache[key] = hit
         return hit[1], hit[2]
 
+    def fp8_eligible(self):
+        """3x3 convolutions the e4m3 kernel serves (csrc/fp8.hip): 128 / 256 / 512 input channels, output channels a multiple of 128."""
+        return self.k == 3 and self.pad == 1 and self.cin_p in (128, 256, 512) and self.cout_p % 128 == 0 and not self.stem
+
+    def fp8_pack(self, act_scale):
+        """(e4m3 weights [Cout, 9*Cin] as uint8, dq [Cout] fp32): w * s_w[co] rounded to e4m3 with s_w = 448 / max|w[co]|, and the
+        factor 1 / (act_scale * s_w[co]) that brings the fp32 accumulator back to the convolution's scale."""
+        key = ("fp8", float(act_scale))
+        sig = self._sig(False)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                w = self.conv.weight.detach().float()
+                s_w = 448.0 / w.abs().amax(dim=(1, 2, 3)).clamp_min(1e-30)
+                wq = (w * s_w.view(-1, 1, 1, 1)).clamp_(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+                out = wq.new_zeros(self.cout_p, self.k, self.k, self.cin_p)
+                out[: w.shape[0], :, :, : w.shape[1]] = wq.permute(0, 2, 3, 1)
+                dq = self._padded(1.0 / (float(act_scale) * s_w), 0.0).contiguous()
+                hit = (sig, out.reshape(self.cout_p, -1).contiguous(), dq)
+            self._cache[key] = hit
+        return hit[1], hit[2]
+
+    def eval_affine(self, stats_epoch):
+        """(scale, shift) of the eval-mode BatchNorm (running statistics), for paths that cannot fold it into the weights."""
+        key = ("affine",)
+        sig = (self._sig(True), stats_epoch)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != sig:
+            bn = self.bn
+            with torch.no_grad():
+                scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                shift = bn.bias.float() - bn.running_mean.float() * scale
+                hit = (sig, self._padded(scale, 1.0).contiguous(), self._padded(shift, 0.0).contiguous())
+            self._cache[key] = hit
+        return hit[1], hit[2]
+
     def running(self):
         """running_mean / running_var tensors the finalize kernel updates in place (padded copies when
         the unit is channel-padded; `writeback` copies them home)."""
@@ -178,8 +214,14 @@ class resnet(nn.Module):
       * eval mode: BN is folded into the packed weights; bias, residual add and ReLU run in the conv epilogue.
     """
 
-    def __init__(self, out_layers, depth=152, width=64, blocks=None, dtype=torch.bfloat16):
+    def __init__(self, out_layers, depth=152, width=64, blocks=None, dtype=torch.bfloat16, fp8=False, fp8_act_scale=16.0):
         super().__init__()
+        if fp8 and dtype != torch.bfloat16:
+            raise SrError("the fp8 path of the 3x3 convolutions sits inside a bf16 backbone (dtype=torch.bfloat16)")
+        # fp8: the bottlenecks' 3x3 convolutions (the matrix-bound family) take e4m3 activations and weights on the 2x-rate
+        # scaled MFMA (csrc/fp8.hip; BASELINE config 5).  Activations are quantised as e4m3(a * fp8_act_scale) by the BatchNorm
+        # apply in front of the conv (post-BN-ReLU values are O(1): 16 keeps them in e4m3's normal range up to 28).
+        self.fp8, self.fp8_act_scale = bool(fp8), float(fp8_act_scale)
         self.model = _ResNetParams(depth, width, blocks)
         for p in self.model.parameters():               # model.py:17-18
             p.requires_grad = False
@@ -250,7 +292,7 @@ class resnet(nn.Module):
                 and u.cin_p in (64, 128, 256, 512) and u.cout_p >= 4 * u.cin_p
                 and n_pixels >= 256 * u.cin_p)    # (below ~256*C pixels the fixed cost of the fp64 finalize loses to launch 1)
 
-    def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False, then=None, twin=None):
+    def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False, then=None, twin=None, quant_out=False):
         """`then`: the unit that consumes this one's output next (lets BN-apply and the consumer's Gram pass share one sweep).
         `twin` = (unit of a weight-identical backbone, its momentum): its running statistics are updated from the same batch."""
         dt = self.dtype
@@ -259,9 +301,17 @@ class resnet(nn.Module):
             self._unit_count += 1
             if self._unit_count == hook[0]:
                 hook[1]()
+        f8_in = x.dtype == torch.uint8 and stem_hw is None         # e4m3 activations from the preceding unit (quant_out)
         if not train:
+            if f8_in:                                              # raw fp8 convolution, then the eval-mode affine + ReLU
+                wq, dq = u.fp8_pack(self.fp8_act_scale)
+                y = ops.conv3x3_fp8(x, wq, dq, u.cout_p, stride=u.stride)
+                sc, sh = u.eval_affine(self._stats_epoch)
+                return ops.bn_apply(y, sc, sh, res=res, relu=relu, out=y)
             w, b = u.folded(dt, self._stats_epoch)
             y = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=b, res=res, relu=relu, stem_hw=stem_hw)
+            if quant_out:
+                return ops.quantize_fp8(y, self.fp8_act_scale)
             return ops.maxpool3x3s2(y) if pool_after else y
         w, gamma, beta = u.raw(dt)
         rm, rv, padded = u.running()
@@ -293,9 +343,15 @@ class resnet(nn.Module):
                 scale, shift = ops.bn_finalize(st, x.shape[0] * Ho * Wo, gamma, beta, rm, rv, momentum, u.bn.eps, twin=tw)
             done()
             return ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=shift, escale=scale, res=res, relu=relu)
-        y, st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, want_stats=True, stem_hw=stem_hw)
+        if f8_in:
+            wq, dq = u.fp8_pack(self.fp8_act_scale)
+            y, st = ops.conv3x3_fp8(x, wq, dq, u.cout_p, stride=u.stride, want_stats=True)
+        else:
+            y, st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, want_stats=True, stem_hw=stem_hw)
         scale, shift = ops.bn_finalize(st, y.numel() // u.cout_p, gamma, beta, rm, rv, momentum, u.bn.eps, twin=tw)
         done()
+        if quant_out:                                   # BatchNorm + ReLU + e4m3 in one sweep: the fp8 conv's input, half the bytes of bf16
+            return ops.quantize_fp8(y, self.fp8_act_scale, scale, shift, relu=True)
         if pool_after:                                  # BN + ReLU applied inside the pooling window
             return ops.maxpool3x3s2(y, scale, shift)
         if (then is not None and relu and res is None and u.cout_p <= 256 and then.cin_p == u.cout_p
@@ -382,7 +438,9 @@ class resnet(nn.Module):
                 idn = a if ds is None else self._unit(a, ds, train, momentum, relu=False, twin=T(tds))
                 y = a
                 for i, u in enumerate(convs[:-1]):
-                    y = self._unit(y, u, train, momentum, relu=True, then=convs[i + 1] if i + 2 == len(convs) else None, twin=T(tconvs[i]))
+                    q8 = self.fp8 and len(convs) == 3 and i == 0 and convs[1].fp8_eligible()
+                    y = self._unit(y, u, train, momentum, relu=True, then=convs[i + 1] if i + 2 == len(convs) else None, twin=T(tconvs[i]),
+                                   quant_out=q8)
                 a = self._unit(y, convs[-1], train, momentum, relu=True, res=idn, twin=T(tconvs[-1]))
             feat = ops.avgpool(a)
         if train:
@@ -624,15 +682,15 @@ class FCGGNN(nn.Module):
     skipped because a global average of post-ReLU activations is already non-negative.
     """
 
-    def __init__(self, encoder, D_hidden_state, steps=4, backbone=152, dtype=torch.bfloat16, width=64, blocks=None):
+    def __init__(self, encoder, D_hidden_state, steps=4, backbone=152, dtype=torch.bfloat16, width=64, blocks=None, fp8=False):
         super().__init__()
         self.encoder = encoder
         self.dtype = dtype
         nr, nv, nl = encoder.get_num_roles(), encoder.get_num_verbs(), encoder.get_num_labels()
         self.role_emb = nn.Embedding(nr + 1, D_hidden_state, padding_idx=nr)          # model.py:95-97
         self.verb_emb = nn.Embedding(nv, D_hidden_state)                                # model.py:98
-        self.convnet_verbs = resnet(nv, backbone, width, blocks, dtype)                 # model.py:100
-        self.convnet_nouns = resnet(nl, backbone, width, blocks, dtype)                 # model.py:101
+        self.convnet_verbs = resnet(nv, backbone, width, blocks, dtype, fp8=fp8)        # model.py:100
+        self.convnet_nouns = resnet(nl, backbone, width, blocks, dtype, fp8=fp8)        # model.py:101
         if self.convnet_verbs.out_features != D_hidden_state:
             raise SrError("D_hidden_state (%d) must equal the backbone feature width (%d)"
                           % (D_hidden_state, self.convnet_verbs.out_features))

@@ -260,6 +260,42 @@ def bn_apply(x, scale, shift, res=None, relu=True, out=None):
     return out
 
 
+def quantize_fp8(x, act_scale, scale=None, shift=None, relu=False):
+    """e4m3(f(x) * act_scale) with f = [relu](x*scale + shift) -- the BatchNorm-apply that feeds an fp8 convolution -- or identity.
+    Returns a uint8 tensor of x's shape holding OCP e4m3 bytes."""
+    require_gpu(x, scale, shift)
+    Cc = x.shape[-1]
+    out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    check(_timed("bn_apply", 0, x.numel() * (x.element_size() + 1),
+                 lambda: lib().sr_quantize_fp8(x.data_ptr(), ptr(_f32(scale, "scale")), ptr(_f32(shift, "shift")), out.data_ptr(), x.numel() // Cc,
+                                               Cc, int(relu), float(act_scale), dtype_code(x.dtype), stream())), "sr_quantize_fp8")
+    return out
+
+
+def conv3x3_fp8(xq, wq, dq, Cout, stride=1, want_stats=False):
+    """3x3 / pad 1 convolution of e4m3 activations xq [B,H,W,Cin] (uint8 bytes) with e4m3 weights wq [Cout, 9*Cin]; returns the
+    dequantised result in bf16 (and BatchNorm partial statistics)."""
+    require_gpu(xq, wq, dq)
+    if xq.dtype != torch.uint8 or wq.dtype != torch.uint8 or dq.dtype != torch.float32:
+        raise L.SrError("conv3x3_fp8: xq / wq must be uint8 (e4m3 bytes) and dq fp32")
+    B, H, W_, Cin = xq.shape
+    Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
+    if tuple(wq.shape) != (Cout, 9 * Cin) or dq.shape[0] != Cout:
+        raise L.SrError("conv3x3_fp8: weight / scale shapes do not match")
+    y = torch.empty((B, Ho, Wo, Cout), device=xq.device, dtype=torch.bfloat16)
+    stats = None
+    if want_stats:
+        rows = lib().sr_conv3x3_fp8_stats_rows(B * Ho * Wo, Cout)
+        if rows < 0:
+            raise L.SrError("conv3x3_fp8: unsupported shape")
+        stats = torch.empty((rows, 2, Cout), device=xq.device, dtype=torch.float32)
+    flops = 2.0 * B * Ho * Wo * Cout * 9 * Cin
+    check(_timed("conv3x3_fp8", flops, float(xq.numel() + wq.numel() + 2 * y.numel()),
+                 lambda: lib().sr_conv3x3_fp8(xq.data_ptr(), wq.data_ptr(), dq.data_ptr(), y.data_ptr(), ptr(stats), B, H, W_, Cin, Cout, stride,
+                                              stream())), "sr_conv3x3_fp8")
+    return (y, stats) if want_stats else y
+
+
 def maxpool3x3s2(x, scale=None, shift=None):
     require_gpu(x, scale, shift)
     B, H, W_, Cc = x.shape
