@@ -104,6 +104,9 @@ typedef struct sr_conv_args {
                               launch 1 (no_store) -> statistics -> sr_bn_finalize -> launch 2 with escale=scale, bias=shift. */
 } sr_conv_args;
 int sr_conv2d(const sr_conv_args* a, int dtype, void* stream);
+/* rows of `stats` this exact launch writes (the stem runs on a direct-convolution kernel with its own partial layout; every
+ * other launch follows sr_gemm_stats_tiles(M, Cout)).  Fill the geometry fields of `a`; pointers are not read. */
+int sr_conv_stats_rows(const sr_conv_args* a, int dtype);
 
 /* fp32 NCHW image [B,3,H,W] -> zero-padded NHWC4 [B, Hp, Wp, 4] (Hp = (H+7)&~1, Wp = (W+7)&~1)
  * in `dtype`; replaces the layout work cuDNN does for the 7x7 stem (model.py:35). */

@@ -1348,6 +1348,25 @@ extern "C" int sr_gemm_stats_tiles(int M, int N) {
   return (int)v3_plan(M, N, cfg, true).rows;
 }
 
+extern "C" int sr_conv_stats_rows(const sr_conv_args* a, int dtype) {
+  if (!a || a->B <= 0) return SR_ERR_ARG;
+  int Ho, Wo;
+  if (a->stem) {
+    Ho = (a->H + 6 - 7) / 2 + 1; Wo = (a->W + 6 - 7) / 2 + 1;
+    if (dtype == SR_BF16 && use_v3() && !a->res && !a->escale) {
+      const int r = srx_stem_rows(a);
+      if (r != SR_ERR_UNSUPPORTED) return r;
+    }
+  } else {
+    if (a->stride <= 0) return SR_ERR_ARG;
+    Ho = (a->H + 2 * a->pad - a->KH) / a->stride + 1;
+    Wo = (a->W + 2 * a->pad - a->KW) / a->stride + 1;
+  }
+  const long M = (long)a->B * Ho * Wo;
+  if (M <= 0 || M > 0x7fffffffL) return SR_ERR_ARG;
+  return sr_gemm_stats_tiles((int)M, a->Cout);
+}
+
 extern "C" int sr_gemm_tile_cfg(int M, int N, int linear, int out_16bit) {
   if (M <= 0 || N <= 0) return SR_ERR_ARG;
   if ((N & 7) != 0 && out_16bit) return 0;     // (see `launch`: ragged 16-bit outputs take the v2 kernels)
@@ -1399,6 +1418,10 @@ extern "C" int sr_conv2d(const sr_conv_args* a, int dtype, void* stream) {
     k.kp[0].K = 8 * 32;
     // the fake 8th row/8th pixel must stay inside the padded image
     if ((Ho - 1) * 2 + 7 >= Hp || (Wo - 1) * 2 + 7 >= Wp) return SR_ERR_ARG;
+    if (dtype == SR_BF16 && use_v3() && (a->act == SR_ACT_NONE || a->act == SR_ACT_RELU)) {   // direct stem convolution (stem.hip)
+      const int rc = srx_stem_conv(a, stream);
+      if (rc != SR_ERR_UNSUPPORTED) return rc;
+    }
   } else {
     if (a->Cin % bk || (a->Cin & (a->Cin - 1))) return SR_ERR_ARG;  // power of two, >= one K-tile
     if (a->KH != a->KW || (a->KH != 1 && a->KH != 3) || a->KH * a->KW > 31) return SR_ERR_ARG;

@@ -96,11 +96,15 @@ def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_st
         want_stats, y = True, None
     else:
         y = out if out is not None else torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
-    stats = None
-    if want_stats:
-        stats = torch.empty((stats_tiles(B * Ho * Wo, Cout), 2, Cout), device=x.device, dtype=torch.float32)
     a.x, a.w, a.B, a.H, a.W, a.Cin, a.Cout = x.data_ptr(), w.data_ptr(), B, H, W_, Cin, Cout
     a.KH, a.KW, a.stride, a.pad, a.stem = KH, KH, stride, pad, int(stem_hw is not None)
+    a.res, a.escale = ptr(res), ptr(_f32(escale, "escale"))
+    stats = None
+    if want_stats:
+        rows = lib().sr_conv_stats_rows(C.byref(a), dtype_code(x.dtype))
+        if rows <= 0:
+            raise L.SrError("conv2d: no statistics layout for this launch")
+        stats = torch.empty((rows, 2, Cout), device=x.device, dtype=torch.float32)
     a.y = x.data_ptr() if stats_only else y.data_ptr()          # never written when stats_only
     a.bias, a.res, a.act, a.stats = ptr(_f32(bias, "bias")), ptr(res), (ACT_RELU if relu else ACT_NONE), ptr(stats)
     a.escale, a.no_store = ptr(_f32(escale, "escale")), int(stats_only)

@@ -128,6 +128,16 @@ def test_stem_conv(ops, dtype, B, H, W):
     ref = F.conv2d(ref_in, w.float(), stride=2, padding=3)
     y = ops.conv2d(xp, pack_stem(w).cuda(), 64, 7, 2, 3, stem_hw=(H, W))
     close(y.permute(0, 3, 1, 2), ref, dtype)
+    # train-mode form (raw output + BatchNorm partial sums; bf16: the direct-convolution kernel of csrc/stem.hip, whose edge
+    # tiles at 37 x 51 are partly outside the image) and eval-mode form (folded bias + ReLU)
+    y2, stats = ops.conv2d(xp, pack_stem(w).cuda(), 64, 7, 2, 3, stem_hw=(H, W), want_stats=True)
+    assert torch.equal(y2, y)
+    s1, s2 = stats[:, 0].double().sum(0).cpu(), stats[:, 1].double().sum(0).cpu()
+    assert float((s1 - ref.double().sum((0, 2, 3))).abs().max()) <= 1e-4 * float(ref.abs().sum((0, 2, 3)).max())
+    assert float(((s2 - (ref.double() ** 2).sum((0, 2, 3))).abs() / (ref.double() ** 2).sum((0, 2, 3))).max()) <= 1e-4
+    bias = rnd(64, seed=5)
+    y3 = ops.conv2d(xp, pack_stem(w).cuda(), 64, 7, 2, 3, stem_hw=(H, W), bias=bias.cuda(), relu=True)
+    close(y3.permute(0, 3, 1, 2), torch.relu(ref + bias.view(1, -1, 1, 1)), dtype)
 
 
 @pytest.mark.parametrize("dtype", DT)
