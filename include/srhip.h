@@ -108,6 +108,14 @@ int sr_conv2d(const sr_conv_args* a, int dtype, void* stream);
  * other launch follows sr_gemm_stats_tiles(M, Cout)).  Fill the geometry fields of `a`; pointers are not read. */
 int sr_conv_stats_rows(const sr_conv_args* a, int dtype);
 
+/* Stem + BatchNorm + ReLU + 3x3/2 max-pool in ONE launch: y[b,po,qo,c] = max over the 3x3/2 window (pad 1) of
+ * relu(conv7x7/2(xp, w)[.,.,c] * scale[c] + shift[c]), xp / w as for sr_conv2d with stem != 0 (bf16, 64 output channels),
+ * y bf16 [B, Po, Qo, 64] with Po = (Ho-1)/2+1.  Replaces conv1 -> bn1 -> relu -> maxpool of torchvision's ResNet (call site
+ * reference model.py:35) without ever writing the conv1 output: train mode runs sr_conv2d with no_store first (batch statistics
+ * -> sr_bn_finalize -> scale / shift), eval mode passes the folded weights with scale = 1, shift = folded bias. */
+int sr_stem_bn_relu_maxpool(const void* xp, const void* w, const float* scale, const float* shift, void* y, int B, int H, int W,
+                            int dtype, void* stream);
+
 /* fp32 NCHW image [B,3,H,W] -> zero-padded NHWC4 [B, Hp, Wp, 4] (Hp = (H+7)&~1, Wp = (W+7)&~1)
  * in `dtype`; replaces the layout work cuDNN does for the 7x7 stem (model.py:35). */
 int sr_stem_prep(const float* img, void* out, int B, int H, int W, int dtype, void* stream);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "sr_debug_stamps": [_P, _I],
     "sr_conv2d": [C.POINTER(ConvArgs), _I, _P],
     "sr_conv_stats_rows": [C.POINTER(ConvArgs), _I],
+    "sr_stem_bn_relu_maxpool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sr_stem_prep": [_P, _P, _I, _I, _I, _I, _P],
     "sr_image_prep_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _P],
     "sr_bn_finalize": [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P, _F, _P],

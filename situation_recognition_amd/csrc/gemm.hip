@@ -5,14 +5,23 @@
 // One kernel family serves nn.Linear-shaped GEMMs (GGNN gates, classifiers, their backward GEMMs) and NHWC convolutions
 // (the A rows are gathered on the fly: row m is output pixel (b,ho,wo), K runs over (tap, channel)).
 //
-//   v3 (default): persistent workgroups, 64-byte K-steps through a 3/4-slot LDS ring filled by LDS-DMA, counted vmcnt,
-//                 rolling fragment prefetch, LDS-staged coalesced bf16 epilogue.  Tiles 256x256 / 256x128 / 256x64.
-//   v2 (fallback for N <= 128 with a non-linear epilogue, and SR_GEMM_NO_V3=1): 128-byte K-steps, 3-slot ring, 64x64 per wave.
+//   v3 (default): persistent workgroups; every K-step is a 64-byte row slice in an LDS ring filled by LDS-DMA
+//                 (`buffer_load_dwordx4 ... lds` with a scalar K offset; rows past M / N and padding taps carry an offset beyond
+//                 num_records, so the load writes zeros -- no zero page, no branch); counted vmcnt, never 0 in the loop.
+//                 256x256 tile: 8 waves, FIVE ring slots of 32 KiB (the whole 160 KiB; the epilogue's staging strips live in the
+//                 slot the tile's last step was read from), four steps in flight, the two wave groups HALF A STEP apart
+//                 (one loads while the other multiplies).  256x128 / 256x64 tiles: 4 waves, 3 slots, two workgroups per CU,
+//                 lock-step.  Straight-line step: no rolling fragment prefetch (measured slower), epilogue kind a template
+//                 parameter, 16-bit outputs leave through per-wave LDS staging strips as 16-byte coalesced stores.
+//   v2 (fallback for N <= 128 with a non-linear epilogue, ragged 16-bit N, and SR_GEMM_NO_V3=1): 128-byte K-steps, 3-slot
+//                 ring filled by LDS-DMA with per-lane pointers (padding taps and row tails read a zero page), 64x64 per wave.
+//   Launches that other files serve better are handed over before dispatch: the output-heavy 1x1 convolutions (expand.hip) and the
+//   7x7 stem (stem.hip); the fp8 3x3 convolutions have their own entry point (fp8.hip).
 //
-// Common to both: MFMA roles are swapped (weights = MFMA "A", activations = MFMA "B") so each lane ends up with 4 CONSECUTIVE
-// output columns of one output row; the LDS image is lane-linear for the DMA and the bank-conflict swizzle is applied on the
-// per-lane SOURCE address and again on the fragment ds_read_b128 (cdna_hip_programming.md rule 21); convolution padding and
-// row tails read a zero page instead of branching; the workgroup -> tile mapping is XCD-contiguous.
+// Common to v2 and v3: MFMA roles are swapped (weights = MFMA "A", activations = MFMA "B") so each lane ends up with 4
+// CONSECUTIVE output columns of one output row; the LDS image is lane-linear for the DMA and the bank-conflict swizzle is applied
+// on the per-lane SOURCE address and again on the fragment ds_read_b128 (cdna_hip_programming.md rule 21); the
+// workgroup -> tile mapping is XCD-contiguous.
 #include <stdlib.h>
 
 #include "common.h"
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(c
 // v3: 256x256 tile, 8 waves (2 x 4, each 128 x 64 = 8 x 4 MFMA fragments), for N > 128.
 //
 // Same persistent stream of K-steps as v2, but
-//   * K-step = 64-byte rows (32 bf16 / 16 f32); the ring has FOUR 32 KiB slots, THREE steps (96 KiB) in flight per CU;
+//   * K-step = 64-byte rows (32 bf16 / 16 f32); the 256x256 ring has FIVE 32 KiB slots, FOUR steps (128 KiB) in flight per CU;
 //     a 256x256 tile needs 1.5x fewer LDS-DMA bytes per FLOP than 256x128;
 //   * every DMA piece is a `buffer_load_dwordx4 ... lds` with a scalar K offset (no vector address arithmetic per step);
 //   * the K loop is straight-line: wait, barrier, 4 DMA pieces, 12 ds_read_b128, 32 MFMAs, and a scalar countdown to the
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(c
 // 64-byte rows: 16-byte chunk c of row r is stored at chunk position c ^ ((r & 8) >> 2)  (conflict-free for the
 // ds_read_b128 lane groups, checked by enumeration); one DMA piece = 16 rows x 64 B.
 // =====================================================================================================
-// WAVES_N = 4: 256x256 tile, 8 waves, 4-slot ring (128 KiB), one workgroup per CU   -- compute-heavy shapes
+// WAVES_N = 4: 256x256 tile, 8 waves, 5-slot ring (160 KiB), one workgroup per CU   -- compute-heavy shapes
 // WAVES_N = 2: 256x128 tile, 4 waves, 3-slot ring ( 72 KiB), TWO workgroups per CU  -- output-heavy shapes (small K, wide N):
 //              one workgroup's epilogue (stores) overlaps the other's K loop instead of idling the matrix cores.
 // EPI (compile time, keeps the fully unrolled epilogue small enough for the instruction cache):

@@ -62,11 +62,8 @@ __device__ __forceinline__ void stem_body(const StemArgs& p) {
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int r = 0; r < 7; ++r) wf[j][r] = *reinterpret_cast<const bf16x8_t*>(p.w + (j * 16 + frow) * 256 + r * 32 + fgrp * 8);
-  float bv[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? p.bias[j * 16 + fgrp * 4 + r] : 0.f;
+  float* const vec = reinterpret_cast<float*>(smem + 2 * PBUF + 8 * 2048);          // bias in LDS (read per tile: 16 registers saved)
+  if (threadIdx.x < 64) vec[threadIdx.x] = p.bias ? p.bias[threadIdx.x] : 0.f;
 
   // ---- patch loader: 16 pieces of 1 KiB (64 lanes x 16 B) cover the 703 16-byte chunks of a patch; wave w issues pieces w and w+8
   int pvo[2];
@@ -77,10 +74,10 @@ __device__ __forceinline__ void stem_body(const StemArgs& p) {
     pvo[i] = row < 37 ? (row * p.Wp * 8 + c * 16) : SOOB;
   }
   auto issue = [&](long tile, int buf, bool valid) {
-    const int tw = (int)(tile % p.tiles_w);
-    const long t2 = tile / p.tiles_w;
-    const int th = (int)(t2 % p.tiles_h);
-    const long b = t2 / p.tiles_h;
+    const unsigned ut = (unsigned)tile, t2 = ut / (unsigned)p.tiles_w;      // (32-bit: the host checks the tile count)
+    const int tw = (int)(ut - t2 * (unsigned)p.tiles_w);
+    const long b = t2 / (unsigned)p.tiles_h;
+    const int th = (int)(t2 - (unsigned)b * (unsigned)p.tiles_h);
     const bf16_t* base = p.x + ((b * p.Hp + th * 32) * (long)p.Wp + tw * 32) * 4;
     // the range ends with the image batch: rows of a bottom-edge tile past the last image read as zeros
     const long left = ((long)p.B * p.Hp * p.Wp * 4 - (base - p.x)) * 2;
@@ -128,10 +125,10 @@ __device__ __forceinline__ void stem_body(const StemArgs& p) {
       }
     }
     // ---- epilogue
-    const int tw = (int)(tile % p.tiles_w);
-    const long t2 = tile / p.tiles_w;
-    const int th = (int)(t2 % p.tiles_h);
-    const long b = t2 / p.tiles_h;
+    const unsigned ut = (unsigned)tile, t2 = ut / (unsigned)p.tiles_w;      // (32-bit: the host checks the tile count)
+    const int tw = (int)(ut - t2 * (unsigned)p.tiles_w);
+    const long b = t2 / (unsigned)p.tiles_h;
+    const int th = (int)(t2 - (unsigned)b * (unsigned)p.tiles_h);
     const int wo0 = tw * 16;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -139,10 +136,11 @@ __device__ __forceinline__ void stem_body(const StemArgs& p) {
       const bool ok = ho < p.Ho && wo0 + frow < p.Wo;              // this lane's pixel (row ho, column wo0 + frow) exists
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(vec + j * 16 + fgrp * 4);
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = acc[i][j][r] + bv[j][r];
+          v[r] = acc[i][j][r] + bv[r];
           const float m = ok ? v[r] : 0.f;
           s1[j][r] += m;
           s2[j][r] = __builtin_fmaf(m, m, s2[j][r]);
@@ -180,6 +178,156 @@ __device__ __forceinline__ void stem_body(const StemArgs& p) {
   }
 }
 
+// =====================================================================================================
+// Stem + BatchNorm + ReLU + 3x3/2 max-pool in one launch (train mode, second launch of a two-launch scheme; eval mode with the
+// folded affine): the 9.9 GB raw stem tensor of batch 6144 is never written nor read back.
+//   launch 1: stem_conv_kernel with no_store (statistics only), sr_bn_finalize -> scale / shift;
+//   launch 2: this kernel: convolution again, y = relu(conv * scale + shift) into an LDS tile, max over the 3x3 windows, store
+//             the pooled pixels.
+// A workgroup's 16 x 16 conv tile starts at conv row / column 14*t - 1, so that the 7 x 7 pooled pixels 7t .. 7t+6 find all of
+// their 3x3 windows (conv rows 14t-1 .. 14t+13) inside the tile: tiles overlap by two conv rows (31 % more convolution work, on
+// a kernel that is bound by its 2.5 GB of output).  Conv positions outside the image (row / column -1, or past Ho / Wo) enter
+// the pool as 0: every window holds at least one real post-ReLU value >= 0, so this equals the -inf padding of max_pool2d.
+// =====================================================================================================
+struct StemPoolArgs {
+  const bf16_t* x; const bf16_t* w; bf16_t* y;        // y: [B, Po, Qo, 64] pooled
+  const float* scale; const float* shift;              // [64]
+  int B, Hp, Wp, Ho, Wo, Po, Qo, tiles_h, tiles_w;
+};
+
+__device__ __forceinline__ void stem_pool_body(const StemPoolArgs& p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 patch buffers, then the 16 x 16 x 64 bf16 conv tile (32 KiB)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const long ntiles = (long)p.B * p.tiles_h * p.tiles_w;
+  const int G = gridDim.x;
+
+  bf16x8_t wf[4][7];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 7; ++r) wf[j][r] = *reinterpret_cast<const bf16x8_t*>(p.w + (j * 16 + frow) * 256 + r * 32 + fgrp * 8);
+  // scale / shift live in LDS (behind the conv tile) and are read per tile: 32 registers per lane more for fragment prefetch
+  float* const vec = reinterpret_cast<float*>(smem + 2 * PBUF + 32768);
+  if (threadIdx.x < 64) { vec[threadIdx.x] = p.scale[threadIdx.x]; vec[64 + threadIdx.x] = p.shift[threadIdx.x]; }
+
+  // patch chunk q = piece * 64 + lane: row q / 19, 16-byte column q % 19 (2 pixels)
+  int prow_[2], pcol_[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = (wave + i * 8) * 64 + lane;
+    prow_[i] = q / 19; pcol_[i] = q - prow_[i] * 19;
+  }
+  auto issue = [&](long tile, int buf, bool valid) {
+    const unsigned ut = (unsigned)tile, t2 = ut / (unsigned)p.tiles_w;      // (32-bit: the host checks the tile count)
+    const int tw = (int)(ut - t2 * (unsigned)p.tiles_w);
+    const long b = t2 / (unsigned)p.tiles_h;
+    const int th = (int)(t2 - (unsigned)b * (unsigned)p.tiles_h);
+    // patch origin in the padded image: row 2*(14 th - 1) = 28 th - 2, pixel 28 tw - 2 (negative for the first tile row / column:
+    // those chunks are not fetched at all -- their conv positions are forced to 0 below)
+    const int r0 = 28 * th - 2, c0 = 28 * tw - 2;
+    const bf16_t* img = p.x + b * (long)p.Hp * p.Wp * 4;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, valid ? p.Hp * p.Wp * 8 : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = r0 + prow_[i], px = c0 + 2 * pcol_[i];
+      const bool ok = prow_[i] < 37 && row >= 0 && row < p.Hp && px >= 0 && px + 1 < p.Wp;
+      const int vo = ok ? (row * p.Wp + px) * 8 : SOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(smem + buf * PBUF + (wave + i * 8) * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+
+  char* const tilebuf = smem + 2 * PBUF;            // [16 conv rows][16 conv cols][64 ch] bf16: 128 B per pixel
+  const int a_off = (lane & 15) * 16 + fgrp * 16;
+  long tile = blockIdx.x;
+  if (tile < ntiles) issue(tile, 0, true);
+  swait_vm<0>();
+  __syncthreads();
+  int buf = 0;
+  for (; tile < ntiles; tile += G) {
+    swait_vm<1>();                                   // my pieces of this tile's patch: everything but the previous tile's (one) store
+    __builtin_amdgcn_s_barrier();                    // ... and every wave has finished pooling the previous tile
+    asm volatile("" ::: "memory");
+    issue(tile + G, buf ^ 1, tile + G < ntiles);
+    const char* pb = smem + buf * PBUF;
+    buf ^= 1;
+    f32x4_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(pb + (2 * (wave * 2 + i) + r) * PROW + a_off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][r], fa, acc[i][j], 0, 0, 0);
+      }
+    }
+    const unsigned ut = (unsigned)tile, t2 = ut / (unsigned)p.tiles_w;      // (32-bit: the host checks the tile count)
+    const int tw = (int)(ut - t2 * (unsigned)p.tiles_w);
+    const long b = t2 / (unsigned)p.tiles_h;
+    const int th = (int)(t2 - (unsigned)b * (unsigned)p.tiles_h);
+    // ---- BatchNorm + ReLU, conv tile -> LDS (pixel-major, 128 B per pixel; 8 bytes per (lane, j))
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int lr = wave * 2 + i;                   // local conv row; lane's local conv column = frow
+      const int ho = 14 * th - 1 + lr, wo = 14 * tw - 1 + frow;
+      const bool ok = ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(vec + j * 16 + fgrp * 4), sh = *reinterpret_cast<const f32x4_t*>(vec + 64 + j * 16 + fgrp * 4);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ok ? fmaxf(__builtin_fmaf(acc[i][j][r], sc[r], sh[r]), 0.f) : 0.f;
+        bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<uint2*>(tilebuf + (lr * 16 + frow) * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8) =
+            *reinterpret_cast<const uint2*>(pk);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- 3x3/2 max over the tile: work item = (pooled pixel 0..48, 16-byte channel chunk 0..7); 392 of the 512 lanes work
+    const int item = threadIdx.x;
+    const int pp = item >> 3, ch = item & 7;
+    const int ph = pp / 7, pw = pp - ph * 7;
+    u32x4_t best = {0, 0, 0, 0};
+    const bool act = pp < 49;
+    if (act) {
+      float m[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) m[c] = 0.f;       // (all candidates are >= 0)
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+          const int lr = 2 * ph + dh, lc = 2 * pw + dw;           // local conv position (tile origin = conv row 14 th - 1)
+          const u32x4_t t = *reinterpret_cast<const u32x4_t*>(tilebuf + (lr * 16 + lc) * 128 + ((ch ^ (lc & 7)) << 4));
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            m[2 * c] = fmaxf(m[2 * c], __uint_as_float(t[c] << 16));
+            m[2 * c + 1] = fmaxf(m[2 * c + 1], __uint_as_float(t[c] & 0xffff0000u));
+          }
+        }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) best[c] = (__float_as_uint(m[2 * c]) >> 16) | (__float_as_uint(m[2 * c + 1]) & 0xffff0000u);   // (values are exact bf16)
+    }
+    // one store per lane and tile (issued by every lane: lanes without a pooled pixel, and pixels past the pooled image, are
+    // dropped by the descriptor's range check)
+    const int po = 7 * th + ph, qo = 7 * tw + pw;
+    const bool in = act && po < p.Po && qo < p.Qo;
+    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + b * (long)p.Po * p.Qo * 64), 0, p.Po * p.Qo * 128, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(best, srd_o, in ? (po * p.Qo + qo) * 128 + ch * 16 : SOOB, 0, 0);
+  }
+  swait_vm<0>();
+}
+
+__global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs p) { stem_pool_body(p); }
+struct StemPoolTag {};
+
 __global__ __launch_bounds__(512, 2) void stem_conv_kernel(const StemArgs p) { stem_body(p); }
 
 struct StemTag {};
@@ -205,6 +353,26 @@ int srx_stem_rows(const sr_conv_args* a) {
   return (int)stem_grid(ntiles) * 8;
 }
 
+extern "C" int sr_stem_bn_relu_maxpool(const void* xp, const void* w, const float* scale, const float* shift, void* y, int B, int H, int W,
+                                      int dtype, void* stream) {
+  if (!xp || !w || !scale || !shift || !y || B <= 0 || H <= 0 || W <= 0) return SR_ERR_ARG;
+  if (dtype != SR_BF16) return SR_ERR_UNSUPPORTED;
+  StemPoolArgs s;
+  s.x = (const bf16_t*)xp; s.w = (const bf16_t*)w; s.y = (bf16_t*)y; s.scale = scale; s.shift = shift;
+  s.B = B; s.Hp = (H + 6 + 1) & ~1; s.Wp = (W + 6 + 1) & ~1;
+  s.Ho = (H + 6 - 7) / 2 + 1; s.Wo = (W + 6 - 7) / 2 + 1;
+  s.Po = (s.Ho - 1) / 2 + 1; s.Qo = (s.Wo - 1) / 2 + 1;
+  s.tiles_h = (s.Po + 6) / 7; s.tiles_w = (s.Qo + 6) / 7;
+  if ((long)s.Hp * s.Wp * 8 >= 0x7fffffffL || (long)s.Po * s.Qo * 128 >= 0x7fffffffL) return SR_ERR_UNSUPPORTED;
+  const long ntiles = (long)B * s.tiles_h * s.tiles_w;
+  if (ntiles > 0x7fffffffL) return SR_ERR_UNSUPPORTED;
+  constexpr int LDS = 2 * PBUF + 32768 + 512;
+  if (!sr_set_dynamic_lds_tagged<StemPoolTag>(reinterpret_cast<const void*>(&stem_pool_kernel), LDS)) return SR_ERR_LAUNCH;
+  hipLaunchKernelGGL(stem_pool_kernel, dim3(stem_grid(ntiles)), dim3(512), LDS, (hipStream_t)stream, s);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+
 int srx_stem_conv(const sr_conv_args* a, void* stream) {
   if (!stem_enabled() || !a->stem || a->Cout != 64 || a->res || a->escale) return SR_ERR_UNSUPPORTED;
   const int Hp = (a->H + 6 + 1) & ~1, Wp = (a->W + 6 + 1) & ~1;
@@ -215,7 +383,8 @@ int srx_stem_conv(const sr_conv_args* a, void* stream) {
   s.B = a->B; s.Hp = Hp; s.Wp = Wp; s.Ho = Ho; s.Wo = Wo; s.relu = a->act == SR_ACT_RELU; s.no_store = a->no_store;
   s.tiles_h = (Ho + 15) / 16; s.tiles_w = (Wo + 15) / 16;
   const long ntiles = (long)s.B * s.tiles_h * s.tiles_w;
-  constexpr int LDS = 2 * PBUF + 8 * 2048;
+  if (ntiles > 0x7fffffffL) return SR_ERR_UNSUPPORTED;
+  constexpr int LDS = 2 * PBUF + 8 * 2048 + 256;
   if (!sr_set_dynamic_lds_tagged<StemTag>(reinterpret_cast<const void*>(&stem_conv_kernel), LDS)) return SR_ERR_LAUNCH;
   hipLaunchKernelGGL(stem_conv_kernel, dim3(stem_grid(ntiles)), dim3(512), LDS, (hipStream_t)stream, s);
   SR_CHECK_LAUNCH();

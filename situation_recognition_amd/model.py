@@ -233,6 +233,7 @@ class resnet(nn.Module):
         self._units = None
         self.two_pass = True           # train-mode BN of output-heavy 1x1 convs in two conv launches (see _unit)
         self.gram_stats = True         # ... with launch 1 replaced by the input's Gram matrix for the expansion convs (bf16)
+        self.fuse_stem_pool = True     # stem + BN + ReLU + maxpool as one kernel (bf16, 64-channel stem)
         self.use_graphs = False        # eval-mode passes replayed from a captured hipGraph (opt-in: FCGGNN.enable_graphs())
         self._graphs = {}
         self._stats_epoch = 0          # bumped whenever a train-mode pass changed running statistics
@@ -292,6 +293,10 @@ class resnet(nn.Module):
                 and u.cin_p in (64, 128, 256, 512) and u.cout_p >= 4 * u.cin_p
                 and n_pixels >= 256 * u.cin_p)    # (below ~256*C pixels the fixed cost of the fp64 finalize loses to launch 1)
 
+    def _fused_stem(self, u, stem_hw, pool_after):
+        return (self.fuse_stem_pool and stem_hw is not None and pool_after and self.dtype == torch.bfloat16 and u.cout_p == 64
+                and os.environ.get("SR_NO_STEM_DIRECT") != "1")
+
     def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False, then=None, twin=None, quant_out=False):
         """`then`: the unit that consumes this one's output next (lets BN-apply and the consumer's Gram pass share one sweep).
         `twin` = (unit of a weight-identical backbone, its momentum): its running statistics are updated from the same batch."""
@@ -309,6 +314,8 @@ class resnet(nn.Module):
                 sc, sh = u.eval_affine(self._stats_epoch)
                 return ops.bn_apply(y, sc, sh, res=res, relu=relu, out=y)
             w, b = u.folded(dt, self._stats_epoch)
+            if self._fused_stem(u, stem_hw, pool_after):           # conv1 + folded BN + ReLU + maxpool in one launch
+                return ops.stem_bn_relu_maxpool(x, w, torch.ones_like(b), b, stem_hw)
             y = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=b, res=res, relu=relu, stem_hw=stem_hw)
             if quant_out:
                 return ops.quantize_fp8(y, self.fp8_act_scale)
@@ -325,6 +332,14 @@ class resnet(nn.Module):
                 u.writeback(rm, rv)
                 if twin is not None:
                     twin[0].writeback(tw[0], tw[1])
+        if self._fused_stem(u, stem_hw, pool_after):
+            # the stem in two launches: statistics only (nothing written), then conv + BatchNorm + ReLU + max-pool in one kernel --
+            # the raw conv1 output (9.9 GB at batch 6144) is never written nor read back
+            st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, stats_only=True, stem_hw=stem_hw)
+            Ho, Wo = (stem_hw[0] - 1) // 2 + 1, (stem_hw[1] - 1) // 2 + 1
+            scale, shift = ops.bn_finalize(st, x.shape[0] * Ho * Wo, gamma, beta, rm, rv, momentum, u.bn.eps, twin=tw)
+            done()
+            return ops.stem_bn_relu_maxpool(x, w, scale, shift, stem_hw)
         if self.two_pass and u.k == 1 and u.cout_p >= 2 * u.cin_p and u.cout_p > 128 and not pool_after:
             # Output-heavy 1x1 conv (bottleneck expansion / downsample): launch it twice instead of conv -> raw tensor ->
             # elementwise pass.  Launch 1 only produces the batch statistics (nothing is written); launch 2 recomputes the

@@ -122,6 +122,19 @@ def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_st
     return (y, stats) if want_stats else y
 
 
+def stem_bn_relu_maxpool(xp, w, scale, shift, hw):
+    """Fused stem: conv7x7/2 -> scale/shift -> ReLU -> maxpool3x3/2 of the padded NHWC4 image `xp` (see sr_stem_bn_relu_maxpool)."""
+    require_gpu(xp, w, scale, shift)
+    B, (H, W_) = xp.shape[0], hw
+    Ho, Wo = (H - 1) // 2 + 1, (W_ - 1) // 2 + 1
+    y = torch.empty((B, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64), device=xp.device, dtype=xp.dtype)
+    flops = 2.0 * B * Ho * Wo * 64 * 147
+    check(_timed("conv7x7", flops, float(xp.numel() * 2 + y.numel() * 2),
+                 lambda: lib().sr_stem_bn_relu_maxpool(xp.data_ptr(), w.data_ptr(), _f32(scale, "scale").data_ptr(), _f32(shift, "shift").data_ptr(),
+                                                       y.data_ptr(), B, H, W_, dtype_code(xp.dtype), stream())), "sr_stem_bn_relu_maxpool")
+    return y
+
+
 def stem_prep(img, dtype):
     require_gpu(img)
     _f32(img, "img")

@@ -140,6 +140,29 @@ def test_stem_conv(ops, dtype, B, H, W):
     close(y3.permute(0, 3, 1, 2), torch.relu(ref + bias.view(1, -1, 1, 1)), dtype)
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 64, 64), (2, 37, 51), (2, 224, 224), (5, 100, 60)])
+def test_fused_stem_bn_relu_maxpool(ops, B, H, W):
+    """csrc/stem.hip `stem_pool_kernel`: conv1 -> scale/shift -> ReLU -> maxpool(3, 2, 1) in one launch (overlapping 16 x 16 conv
+    tiles, 7 x 7 pooled pixels each; edge tiles partly outside the image) against the unfused fp32 chain, and the train-mode
+    pair (statistics-only launch + finalize + fused launch) against F.batch_norm(training=True)."""
+    dtype = torch.bfloat16
+    img = rnd(B, 3, H, W, seed=1)
+    w = rnd(64, 3, 7, 7, dtype=dtype, seed=2, scale=0.1)
+    xp = ops.stem_prep(img.cuda(), dtype)
+    conv = F.conv2d(img.to(dtype).float(), w.float(), stride=2, padding=3)
+    sc, sh = 0.5 + torch.rand(64), rnd(64, seed=3, scale=0.3)
+    ref = F.max_pool2d(F.relu(conv * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 3, 2, 1)
+    y = ops.stem_bn_relu_maxpool(xp, pack_stem(w).cuda(), sc.cuda(), sh.cuda(), (H, W))
+    assert y.shape == (B, ref.shape[2], ref.shape[3], 64)
+    close(y.permute(0, 3, 1, 2), ref, dtype)
+    gamma, beta = 0.5 + torch.rand(64), rnd(64, seed=4, scale=0.2)
+    st = ops.conv2d(xp, pack_stem(w).cuda(), 64, 7, 2, 3, stem_hw=(H, W), stats_only=True)
+    scale, shift = ops.bn_finalize(st, conv.numel() // 64, gamma.cuda(), beta.cuda(), None, None, 0.1, 1e-5)
+    y2 = ops.stem_bn_relu_maxpool(xp, pack_stem(w).cuda(), scale, shift, (H, W))
+    ref2 = F.max_pool2d(F.relu(F.batch_norm(conv, None, None, gamma, beta, training=True, eps=1e-5)), 3, 2, 1)
+    close(y2.permute(0, 3, 1, 2), ref2, dtype, k=2.0)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_batchnorm_train_two_phase(ops, dtype):
     B, H, W, Cin, Cout = 4, 9, 9, 64, 128
