@@ -262,7 +262,7 @@ def main():
     if not args.no_roofline:                  # (every rank runs the profiled step -- it contains the collectives -- rank 0 reports it)
         # One extra training step, every libsrhip launch bracketed by HIP events on its launch stream (single stream: the
         # two-stream overlap of small batches is switched off so that a launch's duration is its own).
-        # Headline = the dominant kernel family conv_igemm_* (backbone implicit-GEMM convolutions) on the MFMA roofline,
+        # Headline = the dominant kernel family (the backbone convolutions: gemm.hip, expand.hip, stem.hip) on the MFMA roofline,
         # as SURVEY 8(d) bounds it: achieved = sum of ALGORITHMIC FLOPs (2*M*N*K of each convolution once = 23.023 GFLOP per
         # image and pass for ResNet-152) / sum of the launches' durations -- statistics-only launches of the two-launch
         # BatchNorm scheme add their time but no FLOPs.  by_kernel: the same per kernel family, each on the roofline that
@@ -293,8 +293,8 @@ def main():
             return e
 
         conv_tags = ["conv1x1", "conv3x3", "conv7x7", "conv3x3_fp8"]
-        head = entry(conv_tags, "mfma", "conv_igemm_* (backbone implicit-GEMM convolutions, both passes, incl. statistics-only launches)")
-        hbm_view = entry(conv_tags, "hbm", "conv_igemm_*")
+        head = entry(conv_tags, "mfma", "backbone convolutions, both passes, incl. statistics-only launches: conv_igemm_v3_kernel (3x3, reduce 1x1, downsample), conv1x1_ws_kernel (output-heavy 1x1), stem_conv_kernel + stem_pool_kernel (7x7 stem)")
+        hbm_view = entry(conv_tags, "hbm", "backbone convolutions")
         # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately on this exact
         # command: profiles/conv_traffic.json records them with the gfx950 corrections); null for any other configuration
         traffic = None
@@ -305,9 +305,10 @@ def main():
                 traffic = round(t["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
-        by = [entry(["conv3x3"], "mfma", "conv_igemm_* 3x3"),
-              entry(["conv3x3_fp8"], "mfma", "conv3x3_fp8_kernel (e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4; peak = dense fp8)"), entry(["conv1x1"], "hbm", "conv_igemm_* 1x1 (reduce / expansion+residual / downsample)"),
-              entry(["conv7x7"], "mfma", "conv_igemm_* 7x7 stem"),
+        by = [entry(["conv3x3"], "mfma", "conv_igemm_v3_kernel 3x3"),
+              entry(["conv3x3_fp8"], "mfma", "conv3x3_fp8_kernel (e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4; peak = dense fp8)"), 
+              entry(["conv1x1"], "hbm", "1x1 convolutions: conv_igemm_v3_kernel (reduce, downsample) + conv1x1_ws_kernel (expansion + BN + residual + ReLU)"),
+              entry(["conv7x7"], "mfma", "7x7 stem: stem_conv_kernel (statistics pass) + stem_pool_kernel (conv + BN + ReLU + max-pool); FLOPs counted once"),
               entry(["gram"], "hbm", "gram_kernel (Gram-matrix statistics of the expansion convs, fused with the preceding BN-apply)"),
               entry(["bn_apply"], "hbm", "bn_apply_kernel"), entry(["maxpool"], "hbm", "maxpool_kernel"),
               entry(["gemm_gate"], "mfma", "gemm_nt_v3_kernel with GRU gate epilogues (GGNN step: z, r & r*h, candidate & blend)"),

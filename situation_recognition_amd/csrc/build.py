@@ -61,12 +61,19 @@ def build(force=False, verbose=True):
 
 
 def build_stamps():
-    """Diagnostic library with in-kernel cycle stamps in expand.hip (libsrhip_stamps.so; select it with SR_LIB_PATH)."""
+    """Diagnostic library with in-kernel cycle stamps in expand.hip (-DXSTAMPS) and gemm.hip (-DSR_STAMPS, read back with
+    sr_debug_stamps under SR_GEMM_DEBUG=4): libsrhip_stamps.so; select it with SR_LIB_PATH."""
     build(verbose=False)
     hipcc = _hipcc()
-    obj = os.path.join(OBJ, "expand_stamps.o")
-    subprocess.run([hipcc] + FLAGS + ["-DXSTAMPS", "-c", os.path.join(HERE, "expand.hip"), "-o", obj], check=True)
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s != "expand.hip"] + [obj]
+    stamped = {"expand.hip": "-DXSTAMPS", "gemm.hip": "-DSR_STAMPS"}
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s not in stamped]
+    jobs = []
+    for src, flag in stamped.items():
+        obj = os.path.join(OBJ, src.replace(".hip", "_stamps.o"))
+        objs.append(obj)
+        jobs.append([hipcc] + FLAGS + [flag, "-c", os.path.join(HERE, src), "-o", obj])
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        list(ex.map(lambda c: subprocess.run(c, check=True), jobs))
     out = os.path.join(PKG, "libsrhip_stamps.so")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True)
     return out

@@ -100,8 +100,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
   }
 }
 
-// Stage B: 64 channels x 16 chunk-groups per workgroup; fixed summation order (deterministic).  TI = float: the partial
-// rows themselves (few rows -- the conv kernels keep running sums -- so stage A is skipped).
+// Stage B: 16 channels x 64 row groups per workgroup (C/16 workgroups: 64-byte row segments, <= 64 rows per thread with four
+// loads in flight); fixed summation order (deterministic).  TI = float: the partial rows themselves (few rows -- the conv
+// kernels keep running sums -- so stage A is skipped).  [It was 64 channels x 16 groups: 4 workgroups for C = 256 and 32
+// dependent iterations per thread, 16 us per launch; ~220 launches per training step.]
 template <typename TI>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const TI* __restrict__ scratch, int chunks, int C, double inv_count,
                                                            double unbias, const float* __restrict__ gamma,
@@ -109,22 +111,37 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const TI* __restrict_
                                                            float* __restrict__ rvar, float momentum, float eps,
                                                            float* __restrict__ scale, float* __restrict__ shift,
                                                            float* __restrict__ rmean2, float* __restrict__ rvar2, float momentum2) {
-  __shared__ double red[2][16][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;
-  double s1 = 0.0, s2 = 0.0;
+  __shared__ double red[2][64][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + tx;
+  double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
   if (c < C) {
-    for (int t = ty; t < chunks; t += 16) {
-      s1 += (double)scratch[((long)t * 2 + 0) * C + c];
-      s2 += (double)scratch[((long)t * 2 + 1) * C + c];
+    int t = ty;
+    for (; t + 192 < chunks; t += 256) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a1[u] += (double)scratch[((long)(t + 64 * u) * 2 + 0) * C + c];
+        a2[u] += (double)scratch[((long)(t + 64 * u) * 2 + 1) * C + c];
+      }
+    }
+    for (; t < chunks; t += 64) {
+      a1[0] += (double)scratch[((long)t * 2 + 0) * C + c];
+      a2[0] += (double)scratch[((long)t * 2 + 1) * C + c];
     }
   }
-  red[0][ty][tx] = s1;
-  red[1][ty][tx] = s2;
+  red[0][ty][tx] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+  red[1][ty][tx] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+  __syncthreads();
+  if (threadIdx.x < 128) {                    // 4 row-group quarters x 2 sums x 16 channels
+    const int q = threadIdx.x >> 5, w = (threadIdx.x >> 4) & 1;
+    double s = 0.0;
+    for (int t = 0; t < 16; ++t) s += red[w][q * 16 + t][tx];
+    red[w][q * 16][tx] = s;                   // (each thread overwrites only the first row of its own quarter)
+  }
   __syncthreads();
   if (ty != 0 || c >= C) return;
-  s1 = 0.0; s2 = 0.0;
-  for (int t = 0; t < 16; ++t) { s1 += red[0][t][tx]; s2 += red[1][t][tx]; }
+  const double s1 = (red[0][0][tx] + red[0][16][tx]) + (red[0][32][tx] + red[0][48][tx]);
+  const double s2 = (red[1][0][tx] + red[1][16][tx]) + (red[1][32][tx] + red[1][48][tx]);
   const double mean = s1 * inv_count;
   double var = s2 * inv_count - mean * mean;  // biased (what normalisation uses)
   if (var < 0.0) var = 0.0;
@@ -409,7 +426,7 @@ extern "C" int sr_bn_finalize(const float* stats, int tiles, int C, int64_t coun
     return SR_ERR_ARG;
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   if (tiles <= 4096) {              // few partial rows: one kernel, fp64 sums straight from the fp32 rows (<= 256 per thread)
-    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stats, tiles, C,
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, stats, tiles, C,
                        1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
                        running_mean2, running_var2, momentum2);
     SR_CHECK_LAUNCH();
@@ -422,7 +439,7 @@ extern "C" int sr_bn_finalize(const float* stats, int tiles, int C, int64_t coun
   chunks = (tiles + tpc - 1) / tpc;
   hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, stats, tiles, C, tpc,
                      scratch);
-  hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const double*)scratch, chunks, C,
+  hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, (const double*)scratch, chunks, C,
                      1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
                      running_mean2, running_var2, momentum2);
   SR_CHECK_LAUNCH();

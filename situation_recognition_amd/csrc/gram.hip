@@ -275,40 +275,60 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const TI* __restrict__
   out[(long)blockIdx.y * E + e] = (s0 + s1) + (s2 + s3);
 }
 
-// One workgroup per 8 output channels: s1 = w.cs, s2 = w G w in fp64, then the BatchNorm finalize of
-// bn_finalize_kernel (elementwise.hip) for those channels.
-__global__ __launch_bounds__(256) void gram_project_kernel(const double* __restrict__ G, const double* __restrict__ cs,
-                                                           const bf16_t* __restrict__ W, long ldw, int C, int N, double inv_count,
-                                                           double unbias, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ rmean,
-                                                           float* __restrict__ rvar, float momentum, float eps,
-                                                           float* __restrict__ scale, float* __restrict__ shift,
-                                                           float* __restrict__ rmean2, float* __restrict__ rvar2, float momentum2) {
+// One workgroup (1024 threads) per 8 output channels: s1 = w.cs, s2 = w G w in fp64, then the BatchNorm finalize of
+// bn_finalize_kernel (elementwise.hip) for those channels.  Thread (g, kk): rows l of sixteenth g of G, columns kk + 64u
+// (u < 4) -- the w[l][0..7] a step needs are wave-uniform LDS reads (broadcasts), and those were what bounded the first
+// form of this kernel (one column per thread: 4 ds_read_b128 per 8 fp64 FMAs, 27 us per launch); four columns per thread
+// quarter them.  A thread's partial sum is multiplied by w[k] on the spot (the form is linear in it), so only the per-channel
+// totals are reduced across threads.
+__global__ __launch_bounds__(1024) void gram_project_kernel(const double* __restrict__ G, const double* __restrict__ cs,
+                                                            const bf16_t* __restrict__ W, long ldw, int C, int N, double inv_count,
+                                                            double unbias, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, float momentum, float eps,
+                                                            float* __restrict__ scale, float* __restrict__ shift,
+                                                            float* __restrict__ rmean2, float* __restrict__ rvar2, float momentum2) {
   __shared__ double wl[512][8];
-  __shared__ double red[2][4][8];
+  __shared__ double red[2][16][8];
   const int n0 = blockIdx.x * 8, tid = threadIdx.x;
-  for (int i = tid; i < C * 8; i += 256) {
+  for (int i = tid; i < C * 8; i += 1024) {
     const int l = i >> 3, j = i & 7;
     wl[l][j] = n0 + j < N ? (double)(float)W[(long)(n0 + j) * ldw + l] : 0.0;
   }
   __syncthreads();
+  const int g = tid >> 6, kk = tid & 63, lq = C >> 4;
   double s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
-  for (int k = tid; k < C; k += 256) {
-    double a[8];
+  for (int kb = 0; kb < C; kb += 256) {
+    double a[4][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = 0.0;
-    for (int l = 0; l < C; ++l) {
-      const double gv = G[(long)l * C + k];
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = fma(gv, wl[l][j], a[j]);
+      for (int j = 0; j < 8; ++j) a[u][j] = 0.0;
+    const int kbase = kb + kk;                      // columns kbase + 64u; past C (C = 64, 128): read column kk again, weight 0
+    for (int l = g * lq; l < (g + 1) * lq; ++l) {
+      double gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) gv[u] = G[(long)l * C + (kbase + 64 * u < C ? kbase + 64 * u : kk)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double w = wl[l][j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u][j] = fma(gv[u], w, a[u][j]);
+      }
     }
-    const double ck = cs[k];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      s2[j] = fma(a[j], wl[k][j], s2[j]);
-      s1[j] = fma(ck, wl[k][j], s1[j]);
+    for (int u = 0; u < 4; ++u) {
+      const int k = kbase + 64 * u;
+      if (k < C) {
+        const double ck = g == 0 ? cs[k] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s2[j] = fma(a[u][j], wl[k][j], s2[j]);
+          s1[j] = fma(ck, wl[k][j], s1[j]);
+        }
+      }
     }
   }
 #pragma unroll
@@ -326,8 +346,8 @@ __global__ __launch_bounds__(256) void gram_project_kernel(const double* __restr
   __syncthreads();
   if (tid >= 8 || n0 + tid >= N) return;
   const int c = n0 + tid;
-  const double t1 = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
-  const double t2 = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+  double t1 = 0.0, t2 = 0.0;
+  for (int w = 0; w < 16; ++w) { t1 += red[0][w][tid]; t2 += red[1][w][tid]; }
   const double mean = t1 * inv_count;
   double var = t2 * inv_count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -506,7 +526,7 @@ extern "C" int sr_bn_finalize_gram(const float* partials, int64_t npartials, int
   hipLaunchKernelGGL(gram_reduce_kernel<float>, dim3(gx, chunks), dim3(256), 0, st, partials, E, (int)npartials, per, E, stageA);
   hipLaunchKernelGGL(gram_reduce_kernel<double>, dim3(gx, 1), dim3(256), 0, st, (const double*)stageA, E, chunks, chunks, E, scratch);
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  hipLaunchKernelGGL(gram_project_kernel, dim3((N + 7) / 8), dim3(256), 0, st, (const double*)scratch, (const double*)(scratch + (long)C * C),
+  hipLaunchKernelGGL(gram_project_kernel, dim3((N + 7) / 8), dim3(1024), 0, st, (const double*)scratch, (const double*)(scratch + (long)C * C),
                      (const bf16_t*)w, (long)ldw, C, N, 1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps,
                      scale, shift, running_mean2, running_var2, momentum2);
   SR_CHECK_LAUNCH();

@@ -24,6 +24,6 @@ cp $(find $O/trace -name "*agent_info.csv" | head -1) $O/agent_info.csv 2>/dev/n
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 > $O/bench_b6144.json 2> $O/bench_b6144.err; echo "bench rc=$?"
 timeout -k 10 300 python3 tools/layer_breakdown.py 6144 > $O/layer_breakdown_b6144.txt 2>&1
 # keep the merged output small: the raw traces are large
-rm -rf $O/trace $O/fetch/*/*kernel_trace* 2>/dev/null
+rm -rf $O/trace 2>/dev/null
 find $O -name "*.csv" -size +20M -delete
 ls -la $O
