@@ -75,6 +75,9 @@ int srx_conv1x1_expand(const sr_conv_args* a, long M, void* stream);
 // stem.hip: the 7x7/2 stem as a direct convolution (bf16, 64 output channels); rows of partial statistics it writes
 int srx_stem_conv(const sr_conv_args* a, void* stream);
 int srx_stem_rows(const sr_conv_args* a);
+// direct 3x3 convolution of the 64-channel layer (c3d.hip); same convention
+int srx_c3d_conv(const sr_conv_args* a, void* stream);
+int srx_c3d_rows(const sr_conv_args* a);
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }

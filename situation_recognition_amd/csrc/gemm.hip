@@ -1370,6 +1370,10 @@ extern "C" int sr_conv_stats_rows(const sr_conv_args* a, int dtype) {
     if (a->stride <= 0) return SR_ERR_ARG;
     Ho = (a->H + 2 * a->pad - a->KH) / a->stride + 1;
     Wo = (a->W + 2 * a->pad - a->KW) / a->stride + 1;
+    if (dtype == SR_BF16 && use_v3()) {
+      const int r = srx_c3d_rows(a);
+      if (r != SR_ERR_UNSUPPORTED) return r;
+    }
   }
   const long M = (long)a->B * Ho * Wo;
   if (M <= 0 || M > 0x7fffffffL) return SR_ERR_ARG;
@@ -1445,7 +1449,9 @@ extern "C" int sr_conv2d(const sr_conv_args* a, int dtype, void* stream) {
   if (M <= 0 || M > 0x7fffffffL) return SR_ERR_ARG;
   if (a->act != SR_ACT_NONE && a->act != SR_ACT_RELU) return SR_ERR_ARG;
   if (dtype == SR_BF16 && use_v3()) {     // output-heavy 1x1 convolutions: the kernel that overlaps K loop and epilogue (expand.hip)
-    const int rc = srx_conv1x1_expand(a, M, stream);
+    int rc = srx_conv1x1_expand(a, M, stream);
+    if (rc != SR_ERR_UNSUPPORTED) return rc;
+    rc = srx_c3d_conv(a, stream);          // the 64-channel 3x3 layer: direct convolution, weights in registers (c3d.hip)
     if (rc != SR_ERR_UNSUPPORTED) return rc;
   }
   k.kp[0].A = a->x; k.kp[0].W = a->w; k.kp[0].lda = 0; k.kp[0].ldw = k.kp[0].K;

@@ -200,3 +200,32 @@ def test_expand_kernel_options_and_ragged_rows(ops, Cin, Cout, rows):
                        res=idn if use_res else None, relu=bool(relu), out=out[:, :rows])
         close(y.view(rows, Cout), ref)
         assert float((out[:, rows:].float() - 7.0).abs().max()) == 0.0          # nothing written past the last row
+
+
+@pytest.mark.parametrize("B,H", [(3, 56), (40, 56), (90, 56), (5, 24)])
+def test_conv3x3_64_64_direct_kernel(ops, B, H):
+    """layer1's 3x3 (3 launches per pass) on the direct-convolution kernel (csrc/c3d.hip: eight image rows per tile, weights in
+    registers): train-mode form (raw output + BatchNorm partial sums; 1, 2 and 3 tiles per workgroup), statistics-only form and
+    eval form (bias + ReLU), against F.conv2d in fp32 on the bf16-rounded operands; the generic implicit-GEMM kernel
+    (SR_NO_C3_DIRECT=1 is read once per process, so it is reached here through a width the direct kernel does not serve)
+    must agree with it to bf16 rounding."""
+    Cc, W = 64, 56
+    M = B * H * W
+    x = F.relu(rnd(B, H, W, Cc, seed=B)).to(BF)
+    w = rnd(Cc, Cc, 3, 3, seed=B + 1, scale=(Cc * 9) ** -0.5)
+    y, stats = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, want_stats=True)
+    assert stats.shape[0] == min(B * (H // 8), torch.cuda.get_device_properties(0).multi_processor_count) * 4
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1).reshape(M, Cc)
+    close(y.view(M, Cc), ref)
+    s1, s2 = stats[:, 0].double().sum(0), stats[:, 1].double().sum(0)
+    r1, r2 = ref.double().sum(0), (ref.double() ** 2).sum(0)
+    assert float((s1 - r1).abs().max()) < 1e-4 * float(ref.abs().sum(0).max())
+    assert float(((s2 - r2).abs() / r2).max()) < 1e-4
+    st2 = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, stats_only=True)
+    assert torch.equal(st2, stats)
+    bias = 0.3 * torch.randn(Cc, device="cuda")
+    y3 = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, bias=bias, relu=True)
+    close(y3.view(M, Cc), F.relu(ref + bias))
+    for _ in range(3):                                 # bit-reproducible (fixed summation order, no atomics)
+        yb, sb = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, want_stats=True)
+        assert torch.equal(yb, y) and torch.equal(sb, stats)
