@@ -67,7 +67,14 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // SYM (one panel, G = x^T x): only the 16 x 16 blocks on or below the block diagonal of the stored matrix -- B-side fragment
+  // j >= A-side fragment -- are computed (136 of 256 fragment products at P = 256) and stored; the reduction mirrors them.  A
+  // wave's two A-side fragments are rg and FA-1-rg (not 2rg, 2rg+1), so that every wave has FA+1 products per stage: the M
+  // sections of the ping-pong loop are barrier-synchronised and as long as their slowest wave's.
+  constexpr bool SYM = !TWO && !TN;
+  constexpr int FA = P / 16;
   const int rg = wave % RG, ks = wave / RG;
+  const int fa0 = SYM ? rg : 2 * rg, fa1 = SYM ? FA - 1 - rg : 2 * rg + 1;
   const int npa = TN ? p.nqa : (TWO ? 2 : 1), npb = TN ? p.nqb : npa;
   const int quad = blockIdx.x % (npa * npb);
   const long slice = blockIdx.x / (npa * npb);
@@ -198,10 +205,11 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
     const char* imgA = smem + (it % NS) * SLOT;
     const char* imgB = TWO ? imgA + STAGE : imgA;
     bf16x8_t a[2], b[FB];
-    a[0] = frag(imgA, 2 * rg);
-    a[1] = frag(imgA, 2 * rg + 1);
+    a[0] = frag(imgA, fa0);
+    a[1] = frag(imgA, fa1);
 #pragma unroll
-    for (int j = 0; j < FB; ++j) b[j] = frag(imgB, j);
+    for (int j = 0; j < FB; ++j)
+      if (!SYM || j >= fa0) b[j] = frag(imgB, j);
     issue(it + NS - 1);                  // refills the slot stage it-1 used
     if (!FUSE && grp == 1) gram_wait_vm<(NS - 2) * IPS>();      // my pieces of stage it+1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -209,8 +217,8 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < FB; ++j) {
-      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[j], acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[j], acc[1][j], 0, 0, 0);
+      if (!SYM || j >= fa0) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[j], acc[0][j], 0, 0, 0);
+      if (!SYM || j >= fa1) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[j], acc[1][j], 0, 0, 0);
     }
     if (!TN) {
       cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ones, cs[0], 0, 0, 0);
@@ -244,9 +252,10 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
   const int t = lane & 15;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int ca = colA0 + 32 * rg + 16 * i + 4 * g;
+    const int ca = colA0 + 16 * (i == 0 ? fa0 : fa1) + 4 * g;
 #pragma unroll
     for (int j = 0; j < FB; ++j) {
+      if (SYM && j < (i == 0 ? fa0 : fa1)) continue;       // (not computed: the mirror block holds the value)
       const int cb = colB0 + 16 * j + t;
       *reinterpret_cast<float4*>(out + (long)cb * (TN ? p.ldo : (long)p.C) + ca) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
@@ -259,9 +268,17 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
 // over the fp64 scratch.
 template <typename TI>
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const TI* __restrict__ in, long stride, int n, int per_chunk, long E,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, int symC, int mirror) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= E) return;
+  // symC > 0: the Gram part is stored block-lower-triangular (16 x 16 blocks, see gram_kernel SYM): entries above the block
+  // diagonal were never written and are skipped; the last stage (mirror) also writes each strictly-lower entry to its transpose
+  int row = 0, col = 0;
+  const bool gpart = symC > 0 && e < (long)symC * symC;
+  if (gpart) {
+    row = (int)(e / symC); col = (int)(e - (long)row * symC);
+    if ((row >> 4) < (col >> 4)) return;
+  }
   const int t0 = blockIdx.y * per_chunk, t1 = min(n, t0 + per_chunk);
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int t = t0;
@@ -272,7 +289,9 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const TI* __restrict__
     s3 += (double)in[(long)(t + 3) * stride + e];
   }
   for (; t < t1; ++t) s0 += (double)in[(long)t * stride + e];
-  out[(long)blockIdx.y * E + e] = (s0 + s1) + (s2 + s3);
+  const double v = (s0 + s1) + (s2 + s3);
+  out[(long)blockIdx.y * E + e] = v;
+  if (mirror && gpart && (row >> 4) > (col >> 4)) out[(long)col * symC + row] = v;
 }
 
 // One workgroup (1024 threads) per 8 output channels: s1 = w.cs, s2 = w G w in fp64, then the BatchNorm finalize of
@@ -523,8 +542,9 @@ extern "C" int sr_bn_finalize_gram(const float* partials, int64_t npartials, int
   hipStream_t st = (hipStream_t)stream;
   double* stageA = scratch + E;   // [chunks][E]; final fp64 G | colsum at scratch[0..E)
   const unsigned gx = (unsigned)((E + 255) / 256);
-  hipLaunchKernelGGL(gram_reduce_kernel<float>, dim3(gx, chunks), dim3(256), 0, st, partials, E, (int)npartials, per, E, stageA);
-  hipLaunchKernelGGL(gram_reduce_kernel<double>, dim3(gx, 1), dim3(256), 0, st, (const double*)stageA, E, chunks, chunks, E, scratch);
+  const int symC = C <= 256 ? C : 0;       // (C = 512 runs as 2 x 2 panels of 256: all four blocks are computed)
+  hipLaunchKernelGGL(gram_reduce_kernel<float>, dim3(gx, chunks), dim3(256), 0, st, partials, E, (int)npartials, per, E, stageA, symC, 0);
+  hipLaunchKernelGGL(gram_reduce_kernel<double>, dim3(gx, 1), dim3(256), 0, st, (const double*)stageA, E, chunks, chunks, E, scratch, symC, 1);
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   hipLaunchKernelGGL(gram_project_kernel, dim3((N + 7) / 8), dim3(1024), 0, st, (const double*)scratch, (const double*)(scratch + (long)C * C),
                      (const bf16_t*)w, (long)ldw, C, N, 1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps,

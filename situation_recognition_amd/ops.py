@@ -222,8 +222,17 @@ def gram_plan(M, Cc):
     return n.value, f.value
 
 
+def gram_valid_mask(Cc, device="cpu"):
+    """[C, C] bool: the entries of a partial's Gram part that sr_gram / sr_bn_apply_gram WRITE.  For C <= 256 only the 16 x 16 blocks
+    on or below the block diagonal are computed (G is symmetric: sr_bn_finalize_gram mirrors them); C = 512 writes all of it."""
+    if Cc > 256:
+        return torch.ones(Cc, Cc, dtype=torch.bool, device=device)
+    blk = torch.arange(Cc, device=device) // 16
+    return blk.view(-1, 1) >= blk.view(1, -1)
+
+
 def gram(x2d):
-    """Per-slice partial Gram matrices + column sums of x2d [M, C] (bf16, C in 64/128/256/512)."""
+    """Per-slice partial Gram matrices + column sums of x2d [M, C] (bf16, C in 64/128/256/512); see gram_valid_mask."""
     require_gpu(x2d)
     M, Cc = x2d.shape
     n, f = gram_plan(M, Cc)
