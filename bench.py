@@ -265,7 +265,8 @@ def main():
         # Headline = the dominant kernel family (the backbone convolutions: gemm.hip, expand.hip, stem.hip) on the MFMA roofline,
         # as SURVEY 8(d) bounds it: achieved = sum of ALGORITHMIC FLOPs (2*M*N*K of each convolution once = 23.023 GFLOP per
         # image and pass for ResNet-152) / sum of the launches' durations -- statistics-only launches of the two-launch
-        # BatchNorm scheme add their time but no FLOPs.  by_kernel: the same per kernel family, each on the roofline that
+        # BatchNorm scheme add their time but no FLOPs.  (The Gram-matrix statistics sweeps of the expansion convs are NOT convolution
+        # launches: they are fused with the BatchNorm-apply sweep in front of them and reported as their own by_kernel entry.)  by_kernel: the same per kernel family, each on the roofline that
         # bounds it (3x3 and stem convolutions: MFMA; 1x1 convolutions: HBM; GGNN gate GEMMs: MFMA; the GGNN step's non-GEMM
         # kernels -- aggregate, GRU backward halves -- HBM, bytes as SURVEY 8(d) counts them).
         keep = net.overlap_backbones
