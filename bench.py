@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--global-batch", type=int, default=6144)
+    ap.add_argument("--graphs", default="off", choices=["auto", "on", "off"],
+                    help="replay the backbones' train-mode passes from hipGraphs (auto: per-GPU batch <= 1536); measured: no gain --\n"
+                         "the gaps between a pass's launches are the GPU's dispatch latency, not the host's (82.3 vs 82.5 ms at batch 768)")
     ap.add_argument("--backbone", type=int, default=152)
     ap.add_argument("--T", type=int, default=5)
     ap.add_argument("--res", type=int, default=224)
@@ -200,6 +203,11 @@ def main():
 
     lo, hi = parallel.shard_range(args.global_batch, rank, world)
     B = hi - lo
+    # optional: the frozen backbones' train-mode passes replayed from captured hipGraphs (the first warm-up step runs eagerly and
+    # captures).  Off by default: it removes the host's launch work, which is not what spaces the launches of a pass.
+    use_graphs = args.graphs == "on" or (args.graphs == "auto" and B <= 1536 and not args.shared_backbone)
+    if use_graphs:
+        net.enable_graphs(True, train=True)
     img, verb, nouns = synthetic_batch(enc, B, args.res, dev, seed_shift=rank)
 
     def step():
@@ -256,6 +264,7 @@ def main():
                                "(504 verbs / 190 roles / 2001 labels)" % (args.backbone, args.T, args.global_batch, args.res, args.res),
                    "global_batch": args.global_batch, "per_gpu_batch": B, "parallelism": "dp%d" % world,
                    "backbone_weights": "shared (one pass serves both)" if args.shared_backbone else "two distinct backbones",
+                   "backbone_launch": "hipGraph replay" if use_graphs else "eager",
                    "final_loss": round(final_loss, 4)},
     }
 

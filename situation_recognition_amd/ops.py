@@ -26,6 +26,12 @@ def _timed(tag, flops, nbytes, launch):
     return rc
 
 
+def _capturing():
+    """Inside a hipGraph capture the per-stream scratch caches are bypassed: every capture runs on the same capture stream, so a
+    cached buffer would be shared by graphs that are later replayed concurrently on different streams (the two backbones)."""
+    return torch.cuda.is_current_stream_capturing()
+
+
 def _f32(t, name):
     if t is not None and t.dtype != torch.float32:
         raise L.SrError("%s must be fp32" % name)
@@ -178,10 +184,11 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
     scale = torch.empty(Cc, device=stats.device, dtype=torch.float32)
     shift = torch.empty_like(scale)
     key = (stats.device, torch.cuda.current_stream().cuda_stream)
-    scratch = _BN_SCRATCH.get(key)
+    scratch = None if _capturing() else _BN_SCRATCH.get(key)
     if scratch is None or scratch.shape[2] < Cc:
         scratch = torch.empty((1024, 2, max(Cc, 2048)), device=stats.device, dtype=torch.float64)
-        _BN_SCRATCH[key] = scratch
+        if not _capturing():
+            _BN_SCRATCH[key] = scratch
     check(lib().sr_bn_finalize(stats.data_ptr(), stats.shape[0], Cc, int(count), gamma.data_ptr(), beta.data_ptr(),
                                ptr(running_mean), ptr(running_var), float(momentum), float(eps), scale.data_ptr(),
                                shift.data_ptr(), scratch.data_ptr(), 1024, ptr(rm2), ptr(rv2), float(m2), stream()), "sr_bn_finalize")
@@ -263,10 +270,11 @@ def bn_finalize_gram(part, w, count, gamma, beta, running_mean, running_var, mom
     scale = torch.empty(N, device=part.device, dtype=torch.float32)
     shift = torch.empty_like(scale)
     key = (part.device, torch.cuda.current_stream().cuda_stream)
-    scratch = _GRAM_SCRATCH.get(key)
+    scratch = None if _capturing() else _GRAM_SCRATCH.get(key)
     if scratch is None or scratch.numel() < 66 * E:
         scratch = torch.empty(66 * (512 * 512 + 512), device=part.device, dtype=torch.float64)
-        _GRAM_SCRATCH[key] = scratch
+        if not _capturing():
+            _GRAM_SCRATCH[key] = scratch
     check(lib().sr_bn_finalize_gram(part.data_ptr(), part.shape[0], Cc, w.data_ptr(), w.stride(0), N, dtype_code(w.dtype), int(count),
                                     gamma.data_ptr(), beta.data_ptr(), ptr(running_mean), ptr(running_var), float(momentum),
                                     float(eps), scale.data_ptr(), shift.data_ptr(), scratch.data_ptr(), scratch.numel(), ptr(rm2), ptr(rv2),

@@ -316,3 +316,39 @@ def test_identical_backbones_share_one_train_pass(sra):
     with torch.no_grad():
         shared.convnet_nouns.model.layer1[0].conv1.weight.mul_(1.01)
     assert not shared.convnet_verbs.weights_equal(shared.convnet_nouns)
+
+
+def test_train_mode_graph_replay_equals_eager(sra):
+    """FCGGNN.enable_graphs(train=True): the frozen backbones' train-mode passes replayed from captured hipGraphs (the first step
+    runs eagerly and captures, later steps replay) against the eager model over three steps with different images: logits and
+    every BatchNorm buffer (running statistics: the verb backbone's one update per step, the noun backbone's two;
+    num_batches_tracked) bit-identical, gradients equal -- on both stream arrangements."""
+    import copy
+    m, Enc = sra
+    enc = Enc.synthetic(V=12, NR=9, L=40, R=4)
+    torch.manual_seed(9)
+    a = m.FCGGNN(enc, 512, steps=2, backbone=50, width=16, dtype=torch.bfloat16).cuda().train()
+    b = copy.deepcopy(a)
+    a.enable_graphs(True, train=True)
+    a.drop_seed_base = b.drop_seed_base = 31
+    for step in range(3):
+        img = torch.randn(6, 3, 96, 96, device="cuda")
+        verb = torch.randint(0, 12, (6,), device="cuda")
+        nouns = torch.randint(0, 40, (6, 3, 4), device="cuda")
+        outs = []
+        for net in (a, b):
+            net.zero_grad()
+            pv, pn, pg = net(img, verb)
+            (net.verb_loss(pv, verb) + net.nouns_loss(pn, nouns)).backward()
+            torch.cuda.synchronize()
+            outs.append((pv, pn, pg))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), step
+    assert any(k[0] == "train" for k in a.convnet_verbs._graphs) and any(k[0] == "train" for k in a.convnet_nouns._graphs)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert int(sa["convnet_verbs.model.bn1.num_batches_tracked"]) == 3 and int(sa["convnet_nouns.model.bn1.num_batches_tracked"]) == 6
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        if p.requires_grad:
+            assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-6 * float(q.grad.abs().max())), k
