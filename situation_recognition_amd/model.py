@@ -241,7 +241,6 @@ class resnet(nn.Module):
         self._stats_epoch = 0          # bumped whenever a train-mode pass changed running statistics
         self._pending_tracked = 0      # num_batches_tracked increments not yet written to the buffers
         self._gram_stash = None        # (data_ptr, Gram partials) a fused BN-apply left for the expansion conv that follows
-        self._unit_hook, self._unit_count = None, 0   # (n, fn): fn() is called before this backbone's n-th conv unit of a pass
         self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_counters())
         self.register_load_state_dict_post_hook(lambda m, incompatible: m._after_load())
 
@@ -303,11 +302,6 @@ class resnet(nn.Module):
         """`then`: the unit that consumes this one's output next (lets BN-apply and the consumer's Gram pass share one sweep).
         `twin` = (unit of a weight-identical backbone, its momentum): its running statistics are updated from the same batch."""
         dt = self.dtype
-        hook = self._unit_hook
-        if hook is not None:                            # (FCGGNN.forward: phase offset between the two backbones' streams)
-            self._unit_count += 1
-            if self._unit_count == hook[0]:
-                hook[1]()
         f8_in = x.dtype == torch.uint8 and stem_hw is None         # e4m3 activations from the preceding unit (quant_out)
         if not train:
             if f8_in:                                              # raw fp8 convolution, then the eval-mode affine + ReLU
@@ -379,7 +373,7 @@ class resnet(nn.Module):
             return y
         return ops.bn_apply(y, scale, shift, res=res, relu=relu, out=y)
 
-    def forward(self, x, bn_updates=1, twin=None, twin_updates=0):
+    def forward(self, x, bn_updates=1, twin=None, twin_updates=0, prepped=None):
         """`bn_updates`=2 gives the running-statistics state of two consecutive train-mode passes over the
         same batch in one pass (FCGGNN.forward runs convnet_nouns twice on the same images, model.py:176-178).
         `twin`: a second `resnet` with IDENTICAL weights (train mode only): its BatchNorm buffers receive `twin_updates`
@@ -389,7 +383,7 @@ class resnet(nn.Module):
                 return self._graph_forward(x)
             if self.graph_train:
                 return self._graph_forward_train(x, bn_updates)
-        return self._forward_impl(x, bn_updates, twin, twin_updates)
+        return self._forward_impl(x, bn_updates, twin, twin_updates, prepped)
 
     def weights_equal(self, other):
         """Are all convolution / BatchNorm affine parameters of the two backbones identical?  (The reference loads the same
@@ -457,7 +451,21 @@ class resnet(nn.Module):
         self._pending_tracked += bn_updates
         return static_out.clone()
 
-    def _forward_impl(self, x, bn_updates=1, twin=None, twin_updates=0):
+    def prepare_input(self, x):
+        """The stem's input layout (zero-padded NHWC4 in the backbone's dtype) of an image batch: fp32 [B,3,H,W] (reference layout) or
+        decoded uint8 [B,H,W,3] (ToTensor + Normalize fused in).  Returns (tensor, H, W); `forward(..., prepped=)` takes it, so two
+        backbones fed the same images share one layout pass."""
+        if not x.is_cuda:
+            raise SrError("situation_recognition_amd.resnet runs on an MI355X only (got a CPU tensor; no CPU fallback)")
+        u8 = x.dtype == torch.uint8
+        if x.dim() != 4 or (x.shape[3] if u8 else x.shape[1]) != 3:
+            raise SrError("expected an image batch: fp32 [B,3,H,W] (reference layout) or decoded uint8 [B,H,W,3]")
+        with torch.no_grad():
+            if u8:      # decoded images: ToTensor + Normalize fused into the stem's layout kernel (no fp32 batch)
+                return ops.image_prep_u8(x.contiguous(), self.dtype), x.shape[1], x.shape[2]
+            return ops.stem_prep(x.float().contiguous(), self.dtype), x.shape[2], x.shape[3]
+
+    def _forward_impl(self, x, bn_updates=1, twin=None, twin_updates=0, prepped=None):
         if not x.is_cuda:
             raise SrError("situation_recognition_amd.resnet runs on an MI355X only (got a CPU tensor; no CPU fallback)")
         u8 = x.dtype == torch.uint8
@@ -476,12 +484,7 @@ class resnet(nn.Module):
             tm = 1.0 - (1.0 - m) ** twin_updates
         T = lambda tu: None if twin is None else (tu, tm)
         with torch.no_grad():
-            if u8:      # decoded images: ToTensor + Normalize fused into the stem's layout kernel (no fp32 batch)
-                H, W = x.shape[1], x.shape[2]
-                xp = ops.image_prep_u8(x.contiguous(), self.dtype)
-            else:
-                H, W = x.shape[2], x.shape[3]
-                xp = ops.stem_prep(x.float().contiguous(), self.dtype)
+            xp, H, W = prepped if prepped is not None else self.prepare_input(x)
             a = self._unit(xp, stem, train, momentum, relu=True, stem_hw=(H, W), pool_after=True, twin=T(tstem))
             for bi, (convs, ds) in enumerate(blocks):
                 tconvs, tds = tblocks[bi] if twin is not None else ([None] * len(convs), None)
@@ -820,26 +823,17 @@ class FCGGNN(nn.Module):
             side = self._side_streams.get(img.device)
             if side is None:
                 side = self._side_streams[img.device] = torch.cuda.Stream(device=img.device)
+            # Both backbones take the same images: the layout kernel in front of the stem (fp32 NCHW or decoded uint8 -> padded bf16
+            # NHWC4) runs once, on the main stream, and its output feeds both passes.
+            share = self.convnet_verbs.dtype == self.convnet_nouns.dtype and not (self.convnet_verbs.use_graphs or self.convnet_nouns.use_graphs)
+            prepped = self.convnet_verbs.prepare_input(img) if share else None
             side.wait_stream(main)
-            phase = int(os.environ.get("SR_PHASE_UNITS", "0"))
-            if phase > 0:
-                # the noun backbone starts `phase` conv units behind the verb backbone, so that one stream's matrix-bound 3x3
-                # convolutions run beside the other's HBM-bound kernels.  The host enqueues the noun pass first (its stream
-                # waits for the event) -- the event itself is recorded while the verb pass is being enqueued.
-                ev = torch.cuda.Event()
-                self.convnet_verbs._unit_count = 0
-                self.convnet_verbs._unit_hook = (phase, lambda: ev.record(main))
-                pred_verb = self.predict_verb(img, batch_size)
-                self.convnet_verbs._unit_hook = None
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
-                    feat = self.convnet_nouns(img, bn_updates=2)
-                img.record_stream(side)
-            else:
-                with torch.cuda.stream(side):
-                    feat = self.convnet_nouns(img, bn_updates=2)
-                img.record_stream(side)
-                pred_verb = self.predict_verb(img, batch_size)
+            with torch.cuda.stream(side):
+                feat = self.convnet_nouns(img, bn_updates=2, prepped=prepped)
+            img.record_stream(side)
+            if prepped is not None:
+                prepped[0].record_stream(side)
+            pred_verb = self._verb_from_features(self.convnet_verbs(img, prepped=prepped), batch_size)
             main.wait_stream(side)
             feat.record_stream(main)
         else:
