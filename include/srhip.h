@@ -102,8 +102,16 @@ typedef struct sr_conv_args {
   const float* escale;     /* optional per-output-channel multiplier: y = act(acc*escale + bias (+res)) (Cout > 128 only).
                               With no_store it gives train-mode BatchNorm in two conv launches and no elementwise pass:
                               launch 1 (no_store) -> statistics -> sr_bn_finalize -> launch 2 with escale=scale, bias=shift. */
+  const float* in_scale;   /* optional INPUT affine [Cin] (both or neither): the convolution runs on relu(x*in_scale + in_shift), */
+  const float* in_shift;   /* i.e. the preceding layer's BatchNorm + ReLU is applied to x on its way into the matrix cores and the
+                              normalised tensor is never written (torchvision bottleneck: bn2 -> relu -> conv3, call site reference
+                              model.py:35).  Only the launches sr_conv_in_affine_supported() accepts; SR_ERR_UNSUPPORTED otherwise. */
 } sr_conv_args;
 int sr_conv2d(const sr_conv_args* a, int dtype, void* stream);
+/* 1 if sr_conv2d serves this launch (geometry, act, res, stats, no_store as they will be passed) WITH in_scale / in_shift, else 0:
+ * bf16 1x1 / stride 1 expansion convolutions (Cin 64 / 128 / 256, Cout 256 / 512 / 1024, >= 32768 output rows) with a residual and
+ * ReLU.  Pointers other than `res` are not read. */
+int sr_conv_in_affine_supported(const sr_conv_args* a, int dtype);
 /* rows of `stats` this exact launch writes (the stem runs on a direct-convolution kernel with its own partial layout; every
  * other launch follows sr_gemm_stats_tiles(M, Cout)).  Fill the geometry fields of `a`; pointers are not read. */
 int sr_conv_stats_rows(const sr_conv_args* a, int dtype);
@@ -157,6 +165,11 @@ int sr_gram(const void* x, int64_t M, int C, int64_t ldx, int dtype, float* part
  * entry and its normalised form on return; partials as sr_gram (C in {64,128,256}). */
 int sr_bn_apply_gram(void* x, int64_t M, int C, int64_t ldx, int dtype, const float* scale, const float* shift,
                      float* partials, int64_t npartials, void* stream);
+/* As sr_bn_apply_gram, but x is NOT modified: the Gram partials are those of relu(x*scale + shift), which only ever exists in
+ * LDS -- for a consumer that applies the same affine on load (sr_conv2d with in_scale / in_shift; call site reference model.py:35,
+ * bn2 -> relu -> conv3 of a bottleneck). */
+int sr_bn_gram(const void* x, int64_t M, int C, int64_t ldx, int dtype, const float* scale, const float* shift,
+               float* partials, int64_t npartials, void* stream);
 int sr_bn_finalize_gram(const float* partials, int64_t npartials, int C, const void* w, int64_t ldw, int N, int dtype,
                         int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
                         float momentum, float eps, float* scale, float* shift, double* scratch, int64_t scratch_elems,

@@ -39,7 +39,7 @@ class ConvArgs(C.Structure):
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("stem", C.c_int32),
                 ("y", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("act", C.c_int32), ("no_store", C.c_int32),
-                ("stats", C.c_void_p), ("escale", C.c_void_p)]
+                ("stats", C.c_void_p), ("escale", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p)]
 
 
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
@@ -51,6 +51,7 @@ SIGNATURES = {
     "sr_debug_stamps": [_P, _I],
     "sr_conv2d": [C.POINTER(ConvArgs), _I, _P],
     "sr_conv_stats_rows": [C.POINTER(ConvArgs), _I],
+    "sr_conv_in_affine_supported": [C.POINTER(ConvArgs), _I],
     "sr_stem_bn_relu_maxpool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sr_stem_prep": [_P, _P, _I, _I, _I, _I, _P],
     "sr_image_prep_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _P],
@@ -58,6 +59,7 @@ SIGNATURES = {
     "sr_gram_plan": [_L, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "sr_gram": [_P, _L, _I, _L, _I, _P, _L, _P],
     "sr_bn_apply_gram": [_P, _L, _I, _L, _I, _P, _P, _P, _L, _P],
+    "sr_bn_gram": [_P, _L, _I, _L, _I, _P, _P, _P, _L, _P],
     "sr_bn_finalize_gram": [_P, _L, _I, _P, _L, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _P, _P, _F, _P],
     "sr_quantize_fp8": [_P, _P, _P, _P, _L, _I, _I, _F, _I, _P],
     "sr_conv3x3_fp8_stats_rows": [_I, _I],

@@ -72,6 +72,7 @@ inline int sr_num_cus() {
 
 // expand.hip: the output-heavy 1x1 convolutions (internal hand-over from sr_conv2d; SR_ERR_UNSUPPORTED = not one of its shapes)
 int srx_conv1x1_expand(const sr_conv_args* a, long M, void* stream);
+bool srx_conv1x1_in_affine_ok(const sr_conv_args* a, long M);
 // stem.hip: the 7x7/2 stem as a direct convolution (bf16, 64 output channels); rows of partial statistics it writes
 int srx_stem_conv(const sr_conv_args* a, void* stream);
 int srx_stem_rows(const sr_conv_args* a);

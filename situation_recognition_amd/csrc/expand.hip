@@ -38,6 +38,7 @@ struct ExpArgs {
   bf16_t* out; long ldc;
   const float* escale; const float* bias;
   int M, N, K, relu;
+  const float* in_scale; const float* in_shift;   // weight-stationary kernel only: A <- relu(A * in_scale[k] + in_shift[k]) on load
 };
 
 template <int I, int N, typename F>
@@ -368,7 +369,7 @@ __device__ __forceinline__ void expand_body(const ExpArgs& p) {
 // LDS: one 16 KiB tile per barrier (not per K-step), read by all eight waves.  17 LDS bytes per output, no weight traffic,
 // one barrier per tile, the whole K loop of a tile (64 MFMAs per wave) back to back.
 // =====================================================================================================
-template <int NKT, int WN, bool RES, bool RELU>
+template <int NKT, int WN, bool RES, bool RELU, bool INAFF = false>
 __device__ __forceinline__ void ws_body(const ExpArgs& p) {
   constexpr int WM = 8 / WN;                     // wave rows: every wave row works on its own 32 rows of the tile
   constexpr int TM = 32 * WM;                    // rows per tile
@@ -380,6 +381,7 @@ __device__ __forceinline__ void ws_body(const ExpArgs& p) {
   static_assert((D - 1) * OPS + OPS - PPW < 64, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const stg = smem + NSLOT * ASLOT + (threadIdx.x >> 6) * XSTG;
+  float* const inaff = reinterpret_cast<float*>(smem + NSLOT * ASLOT + 8 * XSTG);     // INAFF: [2][K] scale | shift of the input channels
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -452,14 +454,48 @@ __device__ __forceinline__ void ws_body(const ExpArgs& p) {
   }
 #pragma unroll
   for (int s = 0; s < D; ++s) issue(s, s);
+  if (INAFF) {
+    for (int k = threadIdx.x; k < p.K; k += 512) { inaff[k] = p.in_scale[k]; inaff[p.K + k] = p.in_shift[k]; }
+  }
   xwait_vm<0>();
   __syncthreads();
+
+  // INAFF: the activation tile holds the RAW output of the preceding convolution; every lane applies that convolution's BatchNorm
+  // + ReLU to the 16-byte chunks it loaded itself (they hold the same 8 channels of every tile), in LDS, between its own wait
+  // for them and the tile's barrier -- the normalised tensor is never written to memory (it was one more read + write of the
+  // tensor in front of this kernel).  Rows past M are zero-filled and become relu(shift): their output rows are dropped anyway.
+  auto in_affine = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int q = wave + i * 8;
+      if (q >= PIECES) continue;
+      const int c8 = (q / (TM / 16)) * 32 + ec;               // first of the chunk's 8 channels
+      char* const at = smem + slot * ASLOT + a_dst[i] + lane * 16;
+      uint4 v = *reinterpret_cast<const uint4*>(at);
+      const float4 s0 = *reinterpret_cast<const float4*>(inaff + c8), s1 = *reinterpret_cast<const float4*>(inaff + c8 + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(inaff + p.K + c8), h1 = *reinterpret_cast<const float4*>(inaff + p.K + c8 + 4);
+      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+      unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float lo = __builtin_fmaf(__uint_as_float(w[e] << 16), sc[2 * e], sh[2 * e]);
+        float hi = __builtin_fmaf(__uint_as_float(w[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]);
+        lo = lo > 0.f ? lo : 0.f;
+        hi = hi > 0.f ? hi : 0.f;
+        bf16_t pk[2] = {(bf16_t)lo, (bf16_t)hi};
+        w[e] = *reinterpret_cast<const unsigned*>(pk);
+      }
+      *reinterpret_cast<uint4*>(at) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
 
   const int a_off = (wmi * 32 + frow) * 64 + fsw;          // + ks * TM * 64 + i * 1024
   int slot_c = 0, slot_i = D;
   for (int t = 0; t < my_tiles; ++t) {
     // my pieces of tile t: issued D tiles ago, right after that tile's barrier
     xwait_vm<(D - 1) * OPS + OPS - PPW>();
+    if (INAFF) in_affine(slot_c);
     __builtin_amdgcn_s_barrier();                 // the tile is complete; every wave has finished reading tile t-1
     asm volatile("" ::: "memory");
     issue(t + D, slot_i);                         // (refills the slot of tile t-2: NSLOT = D + 2)
@@ -521,8 +557,8 @@ __device__ __forceinline__ void ws_body(const ExpArgs& p) {
   xwait_vm<0>();
 }
 
-template <int NKT, int WN, bool RES, bool RELU>
-__global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ExpArgs p) { ws_body<NKT, WN, RES, RELU>(p); }
+template <int NKT, int WN, bool RES, bool RELU, bool INAFF = false>
+__global__ __launch_bounds__(512, 2) void conv1x1_ws_kernel(const ExpArgs p) { ws_body<NKT, WN, RES, RELU, INAFF>(p); }
 
 // (thin kernel around a __device__ body: with the generic lambdas inside the __global__ function itself hipcc's HOST pass
 //  silently drops the kernel's launch stub and the library no longer links)
@@ -535,29 +571,32 @@ inline bool expand_enabled() {
 }
 
 template <int NKT, int NSLOT, bool RES, bool RELU, bool PP> struct XTag {};
-template <int NKT, int WN, bool RES, bool RELU> struct WTag {};
+template <int NKT, int WN, bool RES, bool RELU, bool INAFF = false> struct WTag {};
 
 inline bool ws_enabled() {
   static const bool off = [] { const char* e = getenv("SR_NO_WS"); return e && e[0] == '1'; }();
   return !off;
 }
 
-template <int NKT, int WN, bool RES, bool RELU>
+template <int NKT, int WN, bool RES, bool RELU, bool INAFF = false>
 int launch_ws_v(const ExpArgs& a, hipStream_t st) {
   constexpr int TM = 32 * (8 / WN), ASLOT = TM * NKT * 64, NSLOT = ASLOT <= 8192 ? 8 : (ASLOT <= 16384 ? 6 : 4);
-  const size_t lds = (size_t)NSLOT * ASLOT + 8 * XSTG;
+  const size_t lds = (size_t)NSLOT * ASLOT + 8 * XSTG + (INAFF ? NKT * 32 * 8 : 0);
   const int nh = a.N / (WN * 64);
   const long ntile = ((long)a.M + TM - 1) / TM;
   long walkers = sr_num_cus() / nh;
   if (walkers > ntile) walkers = ntile;
   if (walkers < 1) walkers = 1;
-  if (!sr_set_dynamic_lds_tagged<WTag<NKT, WN, RES, RELU>>(reinterpret_cast<const void*>(&conv1x1_ws_kernel<NKT, WN, RES, RELU>), (int)lds)) return SR_ERR_LAUNCH;
-  hipLaunchKernelGGL((conv1x1_ws_kernel<NKT, WN, RES, RELU>), dim3((unsigned)(walkers * nh)), dim3(512), lds, st, a);
+  if (!sr_set_dynamic_lds_tagged<WTag<NKT, WN, RES, RELU, INAFF>>(reinterpret_cast<const void*>(&conv1x1_ws_kernel<NKT, WN, RES, RELU, INAFF>), (int)lds)) return SR_ERR_LAUNCH;
+  hipLaunchKernelGGL((conv1x1_ws_kernel<NKT, WN, RES, RELU, INAFF>), dim3((unsigned)(walkers * nh)), dim3(512), lds, st, a);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 template <int NKT, int WN>
 int launch_ws(const ExpArgs& a, hipStream_t st) {
+  if (a.in_scale) {                              // (train-mode expansion conv: identity + ReLU; the caller has checked that form)
+    return launch_ws_v<NKT, WN, true, true, true>(a, st);
+  }
   if (a.res) return a.relu ? launch_ws_v<NKT, WN, true, true>(a, st) : launch_ws_v<NKT, WN, true, false>(a, st);
   return a.relu ? launch_ws_v<NKT, WN, false, true>(a, st) : launch_ws_v<NKT, WN, false, false>(a, st);
 }
@@ -602,7 +641,17 @@ extern "C" int srx_expand_stamps(unsigned long long* host_out) {
 
 // Internal (not part of include/srhip.h): sr_conv2d hands over the launches this kernel serves.  Returns SR_ERR_UNSUPPORTED
 // when the shape is not one of them (the caller then uses the generic kernel).
+// Does the weight-stationary kernel serve this launch WITH an input affine (a->in_scale / in_shift)?  (sr_conv_in_affine_supported)
+bool srx_conv1x1_in_affine_ok(const sr_conv_args* a, long M) {
+  return expand_enabled() && ws_enabled() && a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad == 0 && !a->stem && !a->stats && !a->no_store &&
+         (a->Cout == 256 || a->Cout == 512 || a->Cout == 1024) && (a->Cin == 64 || a->Cin == 128 || a->Cin == 256) && M >= 128 * 256 &&
+         M <= 0x7fffffffL && a->res != nullptr && a->act == SR_ACT_RELU;
+}
+
 int srx_conv1x1_expand(const sr_conv_args* a, long M, void* stream) {
+  if (a->in_scale || a->in_shift) {
+    if (!a->in_scale || !a->in_shift || !srx_conv1x1_in_affine_ok(a, M)) return SR_ERR_UNSUPPORTED;
+  }
   if (!expand_enabled()) return SR_ERR_UNSUPPORTED;
   if (a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->stem || a->stats || a->no_store) return SR_ERR_UNSUPPORTED;
   if (a->Cout % 256 || a->Cout > 1024 || (a->Cin != 64 && a->Cin != 128 && a->Cin != 256)) return SR_ERR_UNSUPPORTED;
@@ -615,6 +664,7 @@ int srx_conv1x1_expand(const sr_conv_args* a, long M, void* stream) {
   x.out = (bf16_t*)a->y; x.ldc = a->Cout;
   x.escale = a->escale; x.bias = a->bias;
   x.M = (int)M; x.N = a->Cout; x.K = a->Cin; x.relu = a->act == SR_ACT_RELU;
+  x.in_scale = a->in_scale; x.in_shift = a->in_shift;
   hipStream_t st = (hipStream_t)stream;
   if (ws_enabled() && (a->Cout == 256 || a->Cout == 512 || a->Cout == 1024)) {     // weight-stationary form
     if (a->Cout == 256) {

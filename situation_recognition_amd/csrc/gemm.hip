@@ -1380,6 +1380,12 @@ extern "C" int sr_conv_stats_rows(const sr_conv_args* a, int dtype) {
   return sr_gemm_stats_tiles((int)M, a->Cout);
 }
 
+extern "C" int sr_conv_in_affine_supported(const sr_conv_args* a, int dtype) {
+  if (!a || a->B <= 0 || a->stride <= 0 || dtype != SR_BF16 || !use_v3() || a->stem) return 0;
+  const long Ho = (a->H + 2 * a->pad - a->KH) / a->stride + 1, Wo = (a->W + 2 * a->pad - a->KW) / a->stride + 1;
+  return srx_conv1x1_in_affine_ok(a, (long)a->B * Ho * Wo) ? 1 : 0;
+}
+
 extern "C" int sr_gemm_tile_cfg(int M, int N, int linear, int out_16bit) {
   if (M <= 0 || N <= 0) return SR_ERR_ARG;
   if ((N & 7) != 0 && out_16bit) return 0;     // (see `launch`: ragged 16-bit outputs take the v2 kernels)
@@ -1448,6 +1454,10 @@ extern "C" int sr_conv2d(const sr_conv_args* a, int dtype, void* stream) {
   const long M = (long)a->B * Ho * Wo;
   if (M <= 0 || M > 0x7fffffffL) return SR_ERR_ARG;
   if (a->act != SR_ACT_NONE && a->act != SR_ACT_RELU) return SR_ERR_ARG;
+  if (a->in_scale || a->in_shift) {       // input affine: only the weight-stationary expansion kernel applies it (never silently dropped)
+    if (dtype != SR_BF16 || !use_v3() || a->stem) return SR_ERR_UNSUPPORTED;
+    return srx_conv1x1_expand(a, M, stream);
+  }
   if (dtype == SR_BF16 && use_v3()) {     // output-heavy 1x1 convolutions: the kernel that overlaps K loop and epilogue (expand.hip)
     int rc = srx_conv1x1_expand(a, M, stream);
     if (rc != SR_ERR_UNSUPPORTED) return rc;

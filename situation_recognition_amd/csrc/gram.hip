@@ -35,6 +35,7 @@ struct GramArgs {
   // in global memory) before it enters the Gram sums -- bn_apply and gram in one pass over the tensor
   const float* scale; const float* shift;
   void* trash;
+  int keep;            // FUSE: 1 = the normalised tensor is written back over x; 0 = it only exists in LDS (its consumer normalises again on load)
   int C;
   float* partials;     // [nslices * KS][C*C + C]
   long pstride;        // C*C + C
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
       v = make_uint4(w[0], w[1], w[2], w[3]);
       *reinterpret_cast<uint4*>(img + j * 8192) = v;
       // exactly one store per piece (rows past the slice: the trash page), so that the vmcnt arithmetic below holds
-      *reinterpret_cast<uint4*>(ok ? (char*)(const_cast<bf16_t*>(p.x) + R * p.ldx + src_off[j]) : (char*)p.trash + tid * 16) = v;
+      *reinterpret_cast<uint4*>(ok && p.keep ? (char*)(const_cast<bf16_t*>(p.x) + R * p.ldx + src_off[j]) : (char*)p.trash + tid * 16) = v;
     }
   };
 
@@ -502,8 +503,8 @@ extern "C" int sr_gram(const void* x, int64_t M, int C, int64_t ldx, int dtype, 
 /* x = relu(x*scale[c] + shift[c]) in place (what sr_bn_apply does after the 3x3 conv of a bottleneck) AND the Gram partials of
  * the result for the expansion conv that follows, in one pass over the tensor (C in {64,128,256}; layout of `partials` as
  * sr_gram). */
-extern "C" int sr_bn_apply_gram(void* x, int64_t M, int C, int64_t ldx, int dtype, const float* scale, const float* shift,
-                                float* partials, int64_t npartials, void* stream) {
+static int bn_gram_launch(const void* x, int64_t M, int C, int64_t ldx, int dtype, const float* scale, const float* shift,
+                          float* partials, int64_t npartials, int keep, void* stream) {
   GramPlan g;
   if (dtype != SR_BF16 || !x || !partials || !scale || !shift || !gram_plan(M, C, &g) || g.npan != 1 || npartials != g.npartials ||
       ldx < C || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)partials & 15))
@@ -513,7 +514,7 @@ extern "C" int sr_bn_apply_gram(void* x, int64_t M, int C, int64_t ldx, int dtyp
   if (!zero || !trash) return SR_ERR_LAUNCH;
   GramArgs a{};
   a.x = (const bf16_t*)x; a.M = M; a.ldx = ldx; a.C = C; a.partials = partials; a.pstride = (long)C * C + C;
-  a.rows_per_wg = g.rows_per_wg; a.zero = zero; a.scale = scale; a.shift = shift; a.trash = trash;
+  a.rows_per_wg = g.rows_per_wg; a.zero = zero; a.scale = scale; a.shift = shift; a.trash = trash; a.keep = keep;
   hipStream_t st = (hipStream_t)stream;
   int rc;
   switch (C) {
@@ -524,6 +525,18 @@ extern "C" int sr_bn_apply_gram(void* x, int64_t M, int C, int64_t ldx, int dtyp
   if (rc != SR_OK) return rc;
   SR_CHECK_LAUNCH();
   return SR_OK;
+}
+
+extern "C" int sr_bn_apply_gram(void* x, int64_t M, int C, int64_t ldx, int dtype, const float* scale, const float* shift,
+                                float* partials, int64_t npartials, void* stream) {
+  return bn_gram_launch(x, M, C, ldx, dtype, scale, shift, partials, npartials, 1, stream);
+}
+
+/* As sr_bn_apply_gram, but x is left as it is: the Gram partials are those of relu(x*scale + shift), which only ever exists in
+ * LDS.  For a consumer that applies the same affine on load (sr_conv2d with in_scale / in_shift). */
+extern "C" int sr_bn_gram(const void* x, int64_t M, int C, int64_t ldx, int dtype, const float* scale, const float* shift,
+                          float* partials, int64_t npartials, void* stream) {
+  return bn_gram_launch(x, M, C, ldx, dtype, scale, shift, partials, npartials, 0, stream);
 }
 
 extern "C" int sr_bn_finalize_gram(const float* partials, int64_t npartials, int C, const void* w, int64_t ldw, int N, int dtype,

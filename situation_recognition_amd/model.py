@@ -234,6 +234,7 @@ class resnet(nn.Module):
         self.two_pass = True           # train-mode BN of output-heavy 1x1 convs in two conv launches (see _unit)
         self.gram_stats = True         # ... with launch 1 replaced by the input's Gram matrix for the expansion convs (bf16)
         self.fuse_stem_pool = True     # stem + BN + ReLU + maxpool as one kernel (bf16, 64-channel stem)
+        self.lazy_bn2 = os.environ.get("SR_NO_LAZY_BN2") != "1"   # bn2 + ReLU applied by conv3 on load (train mode, bf16)
         self.use_graphs = False        # eval-mode passes replayed from a captured hipGraph (opt-in: FCGGNN.enable_graphs())
         self.graph_train = False       # ... train-mode passes too (small per-GPU batches: ~900 launches of 10-200 us, 3 us apart)
         self._capturing = False
@@ -298,6 +299,12 @@ class resnet(nn.Module):
         return (self.fuse_stem_pool and stem_hw is not None and pool_after and self.dtype == torch.bfloat16 and u.cout_p == 64
                 and os.environ.get("SR_NO_STEM_DIRECT") != "1")
 
+    def _lazy_ok(self, y, then):
+        """Can the expansion unit `then` consume the RAW tensor y and normalise it on load?  (It is always called with the block's
+        identity as residual and ReLU -- the form the kernel serves; geometry is asked of the library.)"""
+        return (then.k == 1 and then.stride == 1 and y.dtype == torch.bfloat16
+                and ops.conv_in_affine_supported(y, then.cout_p, 1, 1, 0, res=y, relu=True))
+
     def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False, then=None, twin=None, quant_out=False):
         """`then`: the unit that consumes this one's output next (lets BN-apply and the consumer's Gram pass share one sweep).
         `twin` = (unit of a weight-identical backbone, its momentum): its running statistics are updated from the same batch."""
@@ -342,18 +349,22 @@ class resnet(nn.Module):
             # cheap GEMM and applies scale/shift (+identity, ReLU) in its epilogue.  HBM traffic per output element drops
             # from 5 accesses (write raw, read raw, read identity, write) to 2 (read identity, write).
             Ho, Wo = (x.shape[1] - 1) // u.stride + 1, (x.shape[2] - 1) // u.stride + 1
+            in_affine = None
             if self._gram_route(u, x.shape[0] * Ho * Wo):
                 # Expansion conv (N = 4C): its batch statistics follow from the C x C Gram matrix of the input
                 # (sum y^2 = w G w^T), a quarter of the conv's MFMA work and one read of x -- no launch 1 at all.
                 stash, self._gram_stash = self._gram_stash, None
-                part = stash[1] if stash is not None and stash[0] == x.data_ptr() else ops.gram(x.view(-1, u.cin_p))
+                hit = stash is not None and stash[0] == x.data_ptr()
+                part = stash[1] if hit else ops.gram(x.view(-1, u.cin_p))
+                if hit and stash[2] is not None:          # x is still the RAW output of the preceding conv: this conv normalises it on load
+                    in_affine = stash[2]
                 scale, shift = ops.bn_finalize_gram(part, w.view(u.cout_p, u.cin_p), x.shape[0] * Ho * Wo, gamma, beta, rm, rv,
                                                     momentum, u.bn.eps, twin=tw)
             else:
                 st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, stats_only=True)
                 scale, shift = ops.bn_finalize(st, x.shape[0] * Ho * Wo, gamma, beta, rm, rv, momentum, u.bn.eps, twin=tw)
             done()
-            return ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=shift, escale=scale, res=res, relu=relu)
+            return ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=shift, escale=scale, res=res, relu=relu, in_affine=in_affine)
         if f8_in:
             wq, dq = u.fp8_pack(self.fp8_act_scale)
             y, st = ops.conv3x3_fp8(x, wq, dq, u.cout_p, stride=u.stride, want_stats=True)
@@ -369,7 +380,12 @@ class resnet(nn.Module):
                 and self._gram_route(then, y.numel() // u.cout_p)):
             # the consumer is an expansion conv on the Gram route: normalise in place AND accumulate its Gram partials in one
             # sweep over y (`sr_bn_apply_gram`) instead of bn_apply now and a second read of the same tensor by sr_gram
-            self._gram_stash = (y.data_ptr(), ops.bn_apply_gram(y.view(-1, u.cout_p), scale, shift))
+            if self.lazy_bn2 and self._lazy_ok(y, then):
+                # ... and the normalised tensor need not exist at all: the Gram sweep normalises in LDS only and the expansion conv
+                # applies the same scale / shift + ReLU to the raw tensor on load (one write + two reads of y instead of two + two)
+                self._gram_stash = (y.data_ptr(), ops.bn_gram(y.view(-1, u.cout_p), scale, shift), (scale, shift))
+                return y
+            self._gram_stash = (y.data_ptr(), ops.bn_apply_gram(y.view(-1, u.cout_p), scale, shift), None)
             return y
         return ops.bn_apply(y, scale, shift, res=res, relu=relu, out=y)
 

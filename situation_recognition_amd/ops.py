@@ -85,10 +85,25 @@ def stats_tiles(M, N):
     return lib().sr_gemm_stats_tiles(int(M), int(N))
 
 
+def _conv_geometry(a, x, Cout, KH, stride, pad, res, relu):
+    a.B, a.H, a.W, a.Cin, a.Cout = x.shape[0], x.shape[1], x.shape[2], x.shape[3], Cout
+    a.KH, a.KW, a.stride, a.pad, a.stem = KH, KH, stride, pad, 0
+    a.res, a.act = ptr(res), (ACT_RELU if relu else ACT_NONE)
+
+
+def conv_in_affine_supported(x, Cout, KH, stride, pad, res, relu):
+    """Will conv2d(x, ..., in_affine=...) be served (the expansion-conv kernel that normalises its input on load)?"""
+    a = L.ConvArgs()
+    _conv_geometry(a, x, Cout, KH, stride, pad, res, relu)
+    return lib().sr_conv_in_affine_supported(C.byref(a), dtype_code(x.dtype)) == 1
+
+
 def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_stats=False, stem_hw=None, escale=None,
-           stats_only=False, out=None):
+           stats_only=False, out=None, in_affine=None):
     """x: NHWC [B,H,W,Cin] (or, with stem_hw=(H,W), the padded NHWC4 image from stem_prep);
-    w: packed [Cout, KH*KW*Cin] (stem: [Cout, 256]).  Returns y [B,Ho,Wo,Cout] (and stats partials)."""
+    w: packed [Cout, KH*KW*Cin] (stem: [Cout, 256]).  Returns y [B,Ho,Wo,Cout] (and stats partials).
+    in_affine = (scale, shift) over the INPUT channels: the convolution runs on relu(x*scale + shift) (see conv_in_affine_supported;
+    an unsupported launch raises -- the affine is never dropped)."""
     require_gpu(x, w, bias, res)
     a = L.ConvArgs()
     B = x.shape[0]
@@ -114,6 +129,9 @@ def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_st
     a.y = x.data_ptr() if stats_only else y.data_ptr()          # never written when stats_only
     a.bias, a.res, a.act, a.stats = ptr(_f32(bias, "bias")), ptr(res), (ACT_RELU if relu else ACT_NONE), ptr(stats)
     a.escale, a.no_store = ptr(_f32(escale, "escale")), int(stats_only)
+    if in_affine is not None:
+        require_gpu(*in_affine)
+        a.in_scale, a.in_shift = _f32(in_affine[0], "in_scale").data_ptr(), _f32(in_affine[1], "in_shift").data_ptr()
     if res is not None and (tuple(res.shape) != (B, Ho, Wo, Cout) or res.dtype != x.dtype):
         raise L.SrError("conv2d: residual shape/dtype mismatch")
     flops = 2.0 * B * Ho * Wo * Cout * KH * KH * Cin
@@ -258,6 +276,18 @@ def bn_apply_gram(x2d, scale, shift):
     check(_timed("gram", 0.0, 4.0 * M * Cc, lambda: lib().sr_bn_apply_gram(x2d.data_ptr(), M, Cc, x2d.stride(0), dtype_code(x2d.dtype),
                                                                           scale.data_ptr(), shift.data_ptr(), part.data_ptr(), n,
                                                                           stream())), "sr_bn_apply_gram")
+    return part
+
+
+def bn_gram(x2d, scale, shift):
+    """Gram partials of relu(x2d*scale + shift); x2d [M, C] itself is NOT modified (its consumer applies the affine on load)."""
+    require_gpu(x2d, scale, shift)
+    M, Cc = x2d.shape
+    n, f = gram_plan(M, Cc)
+    part = torch.empty((n, f), device=x2d.device, dtype=torch.float32)
+    check(_timed("gram", 0.0, 2.0 * M * Cc, lambda: lib().sr_bn_gram(x2d.data_ptr(), M, Cc, x2d.stride(0), dtype_code(x2d.dtype),
+                                                                    scale.data_ptr(), shift.data_ptr(), part.data_ptr(), n, stream())),
+          "sr_bn_gram")
     return part
 
 

@@ -150,7 +150,7 @@ def test_gram_statistics_route_matches_statistics_only_launch_in_the_backbone():
     net = resnet(None, depth=50, dtype=torch.bfloat16).cuda().train()
     img = torch.randn(352, 3, 224, 224, device="cuda").clamp_(-2.2, 2.7)
     seen, last_x = [], {}
-    gram0, fin0, fused0 = ops.gram, ops.bn_finalize_gram, ops.bn_apply_gram
+    gram0, fin0, fused0, lazy0 = ops.gram, ops.bn_finalize_gram, ops.bn_apply_gram, ops.bn_gram
 
     def gram(x2d):
         last_x["x"] = x2d
@@ -161,6 +161,11 @@ def test_gram_statistics_route_matches_statistics_only_launch_in_the_backbone():
         last_x["x"] = x2d
         return part
 
+    def lazy(x2d, scale, shift):                 # ... or the Gram partials alone: the expansion conv normalises the raw tensor on load
+        part = lazy0(x2d, scale, shift)
+        last_x["x"] = ops.bn_apply(x2d, scale, shift, relu=True)        # (a copy: what the conv will see)
+        return part
+
     def fin(part, w, count, gamma, beta, rm, rv, momentum, eps, twin=None):
         scale, shift = fin0(part, w, count, gamma, beta, rm, rv, momentum, eps, twin=twin)
         x2d = last_x["x"]
@@ -169,11 +174,11 @@ def test_gram_statistics_route_matches_statistics_only_launch_in_the_backbone():
         seen.append((w.shape[1], float(((scale - s2).abs() / s2.abs().clamp_min(1e-3)).max()), float((shift - h2).abs().max())))
         return scale, shift
 
-    ops.gram, ops.bn_finalize_gram, ops.bn_apply_gram = gram, fin, fused
+    ops.gram, ops.bn_finalize_gram, ops.bn_apply_gram, ops.bn_gram = gram, fin, fused, lazy
     try:
         f = net(img)
     finally:
-        ops.gram, ops.bn_finalize_gram, ops.bn_apply_gram = gram0, fin0, fused0
+        ops.gram, ops.bn_finalize_gram, ops.bn_apply_gram, ops.bn_gram = gram0, fin0, fused0, lazy0
     assert torch.isfinite(f).all()
     assert sorted(set(c for c, _, _ in seen)) == [64, 128, 256] and len(seen) == (3 + 1) + 4 + 6   # (+1: layer1's stride-1 downsample)
     for c, ds, dh in seen:

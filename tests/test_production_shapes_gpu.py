@@ -229,3 +229,32 @@ def test_conv3x3_64_64_direct_kernel(ops, B, H):
     for _ in range(3):                                 # bit-reproducible (fixed summation order, no atomics)
         yb, sb = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, want_stats=True)
         assert torch.equal(yb, y) and torch.equal(sb, stats)
+
+
+@pytest.mark.parametrize("Cin,Cout,H,B", [(256, 1024, 14, 200), (128, 512, 28, 48), (64, 256, 56, 12), (256, 1024, 14, 170)])
+def test_expansion_conv_normalises_its_input_on_load(ops, Cin, Cout, H, B):
+    """bn2 -> relu -> conv3 of a bottleneck without the normalised tensor: `conv2d(..., in_affine=(scale2, shift2))` on the RAW conv2
+    output against the same launch on the tensor `bn_apply` wrote (both round relu(x*scale+shift) to bf16 before the matrix
+    cores: bit-identical), and against the fp32 reference; `bn_gram` (the Gram statistics of the normalised tensor, computed without
+    writing it) against `bn_apply_gram`; an unsupported launch must raise instead of dropping the affine."""
+    M = B * H * H
+    y2 = rnd(B, H, H, Cin, seed=Cin + B)                              # raw conv2 output
+    sc2, sh2 = 0.5 + torch.rand(Cin, device="cuda"), 0.3 * torch.randn(Cin, device="cuda")
+    w = rnd(Cout, Cin, 1, 1, seed=7, scale=Cin ** -0.5)
+    idn = rnd(B, H, H, Cout, seed=8)
+    esc, bias = 0.5 + torch.rand(Cout, device="cuda"), 0.3 * torch.randn(Cout, device="cuda")
+    assert ops.conv_in_affine_supported(y2, Cout, 1, 1, 0, res=idn, relu=True)
+    lazy = ops.conv2d(y2, pack_w(w), Cout, 1, 1, 0, bias=bias, escale=esc, res=idn, relu=True, in_affine=(sc2, sh2))
+    z2 = ops.bn_apply(y2, sc2, sh2, relu=True)
+    eager = ops.conv2d(z2, pack_w(w), Cout, 1, 1, 0, bias=bias, escale=esc, res=idn, relu=True)
+    assert torch.equal(lazy, eager)
+    zf = F.relu(y2.float() * sc2 + sh2).to(BF)
+    ref = F.relu(conv_ref(zf, w, 1, 0) * esc + bias + idn.float().view(M, Cout))
+    close(lazy.view(M, Cout), ref)
+    pa = ops.bn_gram(y2.view(M, Cin), sc2, sh2)
+    keep = y2.clone()
+    pb = ops.bn_apply_gram(keep.view(M, Cin), sc2, sh2)
+    valid = torch.cat([ops.gram_valid_mask(Cin).reshape(-1), torch.ones(Cin, dtype=torch.bool)]).cuda()
+    assert torch.equal(pa[:, valid], pb[:, valid]) and torch.equal(keep, z2)
+    with pytest.raises(Exception):                                     # stride 2: not the expansion form -> loud failure
+        ops.conv2d(y2, pack_w(w), Cout, 1, 2, 0, in_affine=(sc2, sh2))

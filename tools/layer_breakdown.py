@@ -27,7 +27,7 @@ def wrap(name, keyfn):
 
 
 def conv_key(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_stats=False, stem_hw=None, escale=None,
-             stats_only=False, out=None):
+             stats_only=False, out=None, in_affine=None):
     Bn = x.shape[0]
     if stem_hw is not None:
         H, W, Cin = stem_hw[0], stem_hw[1], 3
@@ -40,7 +40,8 @@ def conv_key(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_
     M = Bn * Ho * Wo
     fl = 2.0 * M * Cout * kk * Cin
     by = 2.0 * (x.numel() + w.numel()) + (0 if stats_only else 2.0 * M * Cout) + (2.0 * M * Cout if res is not None else 0)
-    flags = ("S" if want_stats else "") + ("O" if stats_only else "") + ("E" if escale is not None else "") + ("R" if res is not None else "")
+    flags = (("S" if want_stats else "") + ("O" if stats_only else "") + ("E" if escale is not None else "") + ("R" if res is not None else "")
+             + ("A" if in_affine is not None else ""))
     return ("conv%dx%d/%d %4d->%4d @%3d %s" % (KH, KH, stride, Cin, Cout, Ho, flags), fl, by)
 
 
@@ -53,6 +54,7 @@ wrap("conv2d", conv_key)
 wrap("bn_apply", apply_key)
 wrap("gram", lambda x: ("gram C=%4d M=%d" % (x.shape[1], x.shape[0]), 2.0 * x.shape[0] * x.shape[1] ** 2, 2.0 * x.numel()))
 wrap("bn_apply_gram", lambda x, sc, sh: ("bn_apply+gram C=%4d M=%d" % (x.shape[1], x.shape[0]), 2.0 * x.shape[0] * x.shape[1] ** 2, 4.0 * x.numel()))
+wrap("bn_gram", lambda x, sc, sh: ("bn+gram (no write) C=%4d M=%d" % (x.shape[1], x.shape[0]), 2.0 * x.shape[0] * x.shape[1] ** 2, 2.0 * x.numel()))
 wrap("bn_finalize_gram", lambda part, w, *a, **k: ("bn_finalize_gram C=%4d N=%4d" % (w.shape[1], w.shape[0]), 0.0, 4.0 * part.numel()))
 wrap("bn_finalize", lambda st, *a, **k: ("bn_finalize C=%4d tiles=%d" % (st.shape[2], st.shape[0]), 0.0, 4.0 * st.numel()))
 wrap("maxpool3x3s2", lambda x, *a: ("maxpool", 0.0, 2.0 * x.numel() * 1.25))
