@@ -35,7 +35,6 @@ struct GramArgs {
   // in global memory) before it enters the Gram sums -- bn_apply and gram in one pass over the tensor
   const float* scale; const float* shift;
   void* trash;
-  int keep;            // FUSE: 1 = the normalised tensor is written back over x; 0 = it only exists in LDS (its consumer normalises again on load)
   int C;
   float* partials;     // [nslices * KS][C*C + C]
   long pstride;        // C*C + C
@@ -56,10 +55,11 @@ template <int P> __device__ __forceinline__ int gram_swz(int row) {
 // P: panel width (channels a workgroup's Gram block spans per side).  TWO: C = 2P, the block's row and column
 // panels differ and are staged separately.  8 waves = RG row groups (32 channels of the A side each) x KS k-splits
 // (32-pixel sub-chunks of a stage); every stage is 16 KB per panel.
-template <int P, bool TWO, bool TN = false, bool FUSE = false>
+template <int P, bool TWO, bool TN = false, bool FUSE = false, bool KEEP = true>
 __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
   static_assert(!TN || (TWO && P == 256), "TN GEMM mode: separate 256-column panels");
   static_assert(!FUSE || (!TWO && !TN), "fused BatchNorm apply: single panel only");
+  constexpr int SPS = (FUSE && KEEP) ? 2 : 0;     // stores per lane and stage (KEEP: the normalised stage is written back over x)
   constexpr int KS = 256 / P, RG = P / 32, FB = P / 16, SR = 32 * KS;
   constexpr int CPRW = P / 8, ROWB = P * 2, STAGE = SR * ROWB;
   constexpr int NPAN = TWO ? 2 : 1, NS = TWO ? 4 : 8, IPS = 2 * NPAN;
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
       }
       v = make_uint4(w[0], w[1], w[2], w[3]);
       *reinterpret_cast<uint4*>(img + j * 8192) = v;
-      // exactly one store per piece (rows past the slice: the trash page), so that the vmcnt arithmetic below holds
-      *reinterpret_cast<uint4*>(ok && p.keep ? (char*)(const_cast<bf16_t*>(p.x) + R * p.ldx + src_off[j]) : (char*)p.trash + tid * 16) = v;
+      // KEEP: exactly one store per piece (rows past the slice: the trash page), so that the vmcnt arithmetic below holds
+      if (KEEP) *reinterpret_cast<uint4*>(ok ? (char*)(const_cast<bf16_t*>(p.x) + R * p.ldx + src_off[j]) : (char*)p.trash + tid * 16) = v;
     }
   };
 
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
     // a stage is normalised by its loaders right after their own wait for it, at the end of an M section (the fragment
     // registers are dead there): group 0 does stage it+1 there, group 1 -- whose wait sits a barrier earlier -- stage it+2
     normalise(0);                                       // (+2 stores, younger than every DMA so far)
-    if (grp == 1) { gram_wait_vm<(NS - 3) * IPS + 2>(); normalise(1); }
+    if (grp == 1) { gram_wait_vm<(NS - 3) * IPS + SPS>(); normalise(1); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
@@ -232,10 +232,10 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
       // than those of stage it+2 5 + 5 (group 1).  In the first iterations fewer store pairs have been issued yet, so
       // FEWER operations are younger: there the count without any stores is used (stricter, always safe).
       if (grp == 0) {
-        if (it >= NS - 3) gram_wait_vm<(NS - 2) * (IPS + 2)>(); else gram_wait_vm<(NS - 2) * IPS>();
+        if (it >= NS - 3) gram_wait_vm<(NS - 2) * (IPS + SPS)>(); else gram_wait_vm<(NS - 2) * IPS>();
         normalise(it + 1);
       } else {
-        if (it >= NS - 5) gram_wait_vm<(NS - 3) * (IPS + 2)>(); else gram_wait_vm<(NS - 3) * IPS>();
+        if (it >= NS - 5) gram_wait_vm<(NS - 3) * (IPS + SPS)>(); else gram_wait_vm<(NS - 3) * IPS>();
         normalise(it + 2);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my LDS writes are in place before the barrier
@@ -402,11 +402,11 @@ bool gram_plan(int64_t M, int C, GramPlan* g) {
   return true;
 }
 
-template <int P, bool TWO, bool FUSE = false>
+template <int P, bool TWO, bool FUSE = false, bool KEEP = true>
 int gram_launch(const GramArgs& a, const GramPlan& g, hipStream_t st) {
   constexpr int LDS = 131072 + (FUSE ? 2 * P * 4 : 0);
-  if (!sr_set_dynamic_lds<&gram_kernel<P, TWO, false, FUSE>>(LDS)) return SR_ERR_LAUNCH;
-  hipLaunchKernelGGL((gram_kernel<P, TWO, false, FUSE>), dim3((unsigned)(g.nslices * g.npan * g.npan)), dim3(512), LDS, st, a);
+  if (!sr_set_dynamic_lds<&gram_kernel<P, TWO, false, FUSE, KEEP>>(LDS)) return SR_ERR_LAUNCH;
+  hipLaunchKernelGGL((gram_kernel<P, TWO, false, FUSE, KEEP>), dim3((unsigned)(g.nslices * g.npan * g.npan)), dim3(512), LDS, st, a);
   return SR_OK;
 }
 
@@ -514,13 +514,13 @@ static int bn_gram_launch(const void* x, int64_t M, int C, int64_t ldx, int dtyp
   if (!zero || !trash) return SR_ERR_LAUNCH;
   GramArgs a{};
   a.x = (const bf16_t*)x; a.M = M; a.ldx = ldx; a.C = C; a.partials = partials; a.pstride = (long)C * C + C;
-  a.rows_per_wg = g.rows_per_wg; a.zero = zero; a.scale = scale; a.shift = shift; a.trash = trash; a.keep = keep;
+  a.rows_per_wg = g.rows_per_wg; a.zero = zero; a.scale = scale; a.shift = shift; a.trash = trash;
   hipStream_t st = (hipStream_t)stream;
   int rc;
   switch (C) {
-    case 64: rc = gram_launch<64, false, true>(a, g, st); break;
-    case 128: rc = gram_launch<128, false, true>(a, g, st); break;
-    default: rc = gram_launch<256, false, true>(a, g, st); break;
+    case 64: rc = keep ? gram_launch<64, false, true>(a, g, st) : gram_launch<64, false, true, false>(a, g, st); break;
+    case 128: rc = keep ? gram_launch<128, false, true>(a, g, st) : gram_launch<128, false, true, false>(a, g, st); break;
+    default: rc = keep ? gram_launch<256, false, true>(a, g, st) : gram_launch<256, false, true, false>(a, g, st); break;
   }
   if (rc != SR_OK) return rc;
   SR_CHECK_LAUNCH();
