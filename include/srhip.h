@@ -110,7 +110,8 @@ typedef struct sr_conv_args {
 int sr_conv2d(const sr_conv_args* a, int dtype, void* stream);
 /* 1 if sr_conv2d serves this launch (geometry, act, res, stats, no_store as they will be passed) WITH in_scale / in_shift, else 0:
  * bf16 1x1 / stride 1 expansion convolutions (Cin 64 / 128 / 256, Cout 256 / 512 / 1024, >= 32768 output rows) with a residual and
- * ReLU.  Pointers other than `res` are not read. */
+ * ReLU, and the 64-channel 3x3 / stride 1 layer on 56-wide images in its train-mode form (statistics, no bias, no activation).
+ * `res` and `stats` are only tested against NULL; no pointer is read. */
 int sr_conv_in_affine_supported(const sr_conv_args* a, int dtype);
 /* rows of `stats` this exact launch writes (the stem runs on a direct-convolution kernel with its own partial layout; every
  * other launch follows sr_gemm_stats_tiles(M, Cout)).  Fill the geometry fields of `a`; pointers are not read. */

@@ -32,6 +32,7 @@ struct C3Args {
   const float* bias;        // [64] or null
   float* stats;             // [grid * 4][2][64] or null
   int B, H, relu, no_store, tiles_h;
+  const float* in_scale; const float* in_shift;   // [64] or null: the convolution runs on relu(x*in_scale + in_shift) (IN kernels)
 };
 
 constexpr int C3_W = 56, C3_TH = 8, C3_PW = C3_W + 2, C3_PR = C3_TH + 2;
@@ -41,7 +42,7 @@ constexpr int C3_PBYTES = C3_PR * C3_PW * 128;            // 74 240
 constexpr int C3_NP = (C3_PBYTES + 1023) / 1024;          // 73 LDS-DMA pieces
 constexpr int C3_NPW = (C3_NP + 3) / 4;                   // 19 per wave
 constexpr int C3_PBUF = C3_NP * 1024;                     // 74 752 (pieces past the patch are not issued)
-constexpr int C3_STG = 2 * C3_PBUF, C3_STAT = C3_STG + 4 * 2048, C3_BIAS = C3_STAT + 4 * 512, C3_LDS = C3_BIAS + 256;
+constexpr int C3_STG = 2 * C3_PBUF, C3_STAT = C3_STG + 4 * 2048, C3_BIAS = C3_STAT + 4 * 512, C3_INAFF = C3_BIAS + 256, C3_LDS = C3_INAFF + 512;
 constexpr int C3_OOB = (int)0x80000000;
 static_assert(C3_TM % 64 == 0 && C3_LDS <= 160 * 1024, "tile / LDS budget");
 
@@ -67,7 +68,8 @@ __device__ __forceinline__ float c3row16_sum(float v) {
 }
 
 // AFF: bias (+ ReLU) in the epilogue (eval mode: folded BatchNorm).  ST: BatchNorm partial statistics (train mode).
-template <bool AFF, bool ST>
+// IN: the input is the RAW output of the preceding convolution; its BatchNorm + ReLU (in_scale, in_shift) is applied to the patch in LDS.
+template <bool AFF, bool ST, bool IN = false>
 __device__ __forceinline__ void c3_body(const C3Args& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 patch buffers | 4 staging strips | 4 statistics rows | bias
   const int lane = threadIdx.x & 63;
@@ -91,6 +93,8 @@ __device__ __forceinline__ void c3_body(const C3Args& p) {
   float* const lbias = reinterpret_cast<float*>(smem + C3_BIAS);
   lstat[lane] = 0.f; lstat[64 + lane] = 0.f;
   if (threadIdx.x < 64) lbias[threadIdx.x] = p.bias ? p.bias[threadIdx.x] : 0.f;
+  float* const inaff = reinterpret_cast<float*>(smem + C3_INAFF);
+  if (IN && threadIdx.x < 64) { inaff[threadIdx.x] = p.in_scale[threadIdx.x]; inaff[64 + threadIdx.x] = p.in_shift[threadIdx.x]; }
 
   // ---- patch loader.  Piece q = i*4 + wave lands at LDS bytes q*1024 + lane*16 of the buffer: patch pixel pq = q*8 + lane/8, chunk
   // position lane%8, which holds data chunk (lane%8) ^ (pq & 7) of that pixel.  The per-lane source offsets are relative to
@@ -102,8 +106,8 @@ __device__ __forceinline__ void c3_body(const C3Args& p) {
   for (int i = 0; i < C3_NPW; ++i) {
     const int pq = (i * 4 + wave) * 8 + (lane >> 3);
     const int pr = pq / C3_PW, pc = pq - pr * C3_PW;
-    const int v = (pr < C3_PR && pc >= 1 && pc <= C3_W) ? (pr * C3_W + pc - 1) * 128 + (((lane & 7) ^ (pq & 7)) << 4) : C3_OOB;
-    vrel[i] = v;
+    // (bits 0..19: the offset; bits 20..23: the patch row, for the IN kernels' own validity test)
+    vrel[i] = (pr < C3_PR && pc >= 1 && pc <= C3_W) ? (((pr * C3_W + pc - 1) * 128 + (((lane & 7) ^ (pq & 7)) << 4)) | (pr << 20)) : C3_OOB;
   }
   auto issue = [&](long tile, int buf, bool valid) {
     const unsigned ut = (unsigned)tile;
@@ -115,7 +119,7 @@ __device__ __forceinline__ void c3_body(const C3Args& p) {
 #pragma unroll
     for (int i = 0; i < C3_NPW; ++i) {
       if (i * 4 + wave >= C3_NP) continue;          // (wave-uniform; the waits below count back from the youngest operations only)
-      int vo = vrel[i];
+      int vo = vrel[i] < 0 ? C3_OOB : (vrel[i] & 0xfffff);
       if (i < 2) vo = (y0 == 0 && (i * 4 + wave) * 8 + (lane >> 3) < C3_PW) ? C3_OOB : vo;   // (pieces 0..7 hold patch row 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(smem + buf * C3_PBUF + (i * 4 + wave) * 1024), 16, vo, 0,
                                                0, 0);
@@ -139,6 +143,37 @@ __device__ __forceinline__ void c3_body(const C3Args& p) {
   for (; tile < ntiles; tile += G) {
     // my pieces of this tile's patch have landed: everything but the 14 stores of the previous tile's epilogue
     c3wait_vm<2 * C3_FPW>();
+    if constexpr (IN) {
+      // BatchNorm + ReLU of the layer in front, applied to the 16-byte chunks THIS lane loaded (always the same 8 channels: chunk
+      // (lane & 7) ^ (lane >> 3 & 7)), in place, between the lane's own wait for them and the tile's barrier.  Pad pixels and rows
+      // outside the image were zero-filled by the loader and must stay zero: the convolution pads the NORMALISED tensor.
+      const unsigned ut0 = (unsigned)tile;
+      const int y00 = (int)(ut0 - (ut0 / (unsigned)p.tiles_h) * (unsigned)p.tiles_h) * C3_TH;
+      const int c8 = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
+      const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(inaff + c8), s1_ = *reinterpret_cast<const f32x4_t*>(inaff + c8 + 4);
+      const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(inaff + 64 + c8), h1 = *reinterpret_cast<const f32x4_t*>(inaff + 64 + c8 + 4);
+      const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1_[0], s1_[1], s1_[2], s1_[3]}, sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+#pragma unroll
+      for (int i = 0; i < C3_NPW; ++i) {
+        if (i * 4 + wave >= C3_NP) continue;
+        const int row = y00 - 1 + ((vrel[i] >> 20) & 15);
+        if (vrel[i] < 0 || row < 0 || row >= p.H) continue;
+        char* const at = smem + buf * C3_PBUF + (i * 4 + wave) * 1024 + lane * 16;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(at);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float lo = __builtin_fmaf(__uint_as_float(v[e] << 16), sc[2 * e], sh[2 * e]);
+          float hi = __builtin_fmaf(__uint_as_float(v[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]);
+          lo = lo > 0.f ? lo : 0.f;
+          hi = hi > 0.f ? hi : 0.f;
+          bf16_t pk[2] = {(bf16_t)lo, (bf16_t)hi};
+          o[e] = *reinterpret_cast<const unsigned*>(pk);
+        }
+        *reinterpret_cast<u32x4_t*>(at) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                     // ... everybody's have, and everybody has finished reading the other buffer
     asm volatile("" ::: "memory");
     int z;
@@ -287,14 +322,14 @@ __device__ __forceinline__ void c3_body(const C3Args& p) {
   }
 }
 
-template <bool AFF, bool ST>
-__global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(const C3Args p) { c3_body<AFF, ST>(p); }
-template <bool AFF, bool ST> struct C3Tag {};
+template <bool AFF, bool ST, bool IN = false>
+__global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(const C3Args p) { c3_body<AFF, ST, IN>(p); }
+template <bool AFF, bool ST, bool IN = false> struct C3Tag {};
 
-template <bool AFF, bool ST>
+template <bool AFF, bool ST, bool IN = false>
 int c3_launch(const C3Args& s, unsigned grid, hipStream_t st) {
-  if (!sr_set_dynamic_lds_tagged<C3Tag<AFF, ST>>(reinterpret_cast<const void*>(&conv3x3_c64_kernel<AFF, ST>), C3_LDS)) return SR_ERR_LAUNCH;
-  hipLaunchKernelGGL((conv3x3_c64_kernel<AFF, ST>), dim3(grid), dim3(256), C3_LDS, st, s);
+  if (!sr_set_dynamic_lds_tagged<C3Tag<AFF, ST, IN>>(reinterpret_cast<const void*>(&conv3x3_c64_kernel<AFF, ST, IN>), C3_LDS)) return SR_ERR_LAUNCH;
+  hipLaunchKernelGGL((conv3x3_c64_kernel<AFF, ST, IN>), dim3(grid), dim3(256), C3_LDS, st, s);
   return SR_OK;
 }
 
@@ -320,14 +355,27 @@ int srx_c3d_rows(const sr_conv_args* a) {
   return (int)c3_grid((long)a->B * ((a->H + C3_TH - 1) / C3_TH)) * 4;
 }
 
+// Does the direct kernel serve this launch WITH an input affine?  (the train-mode form: raw output + statistics, no bias / ReLU)
+bool srx_c3d_in_affine_ok(const sr_conv_args* a) {
+  return c3_serves(a) && a->act == SR_ACT_NONE && !a->bias && a->stats != nullptr;
+}
+
 int srx_c3d_conv(const sr_conv_args* a, void* stream) {
   if (!c3_serves(a) || (a->act != SR_ACT_NONE && a->act != SR_ACT_RELU)) return SR_ERR_UNSUPPORTED;
+  if ((a->in_scale || a->in_shift) && (!a->in_scale || !a->in_shift || !srx_c3d_in_affine_ok(a))) return SR_ERR_UNSUPPORTED;
   C3Args s;
   s.x = (const bf16_t*)a->x; s.w = (const bf16_t*)a->w; s.y = (bf16_t*)a->y; s.bias = a->bias; s.stats = a->stats;
   s.B = a->B; s.H = a->H; s.relu = a->act == SR_ACT_RELU; s.no_store = a->no_store;
   s.tiles_h = (a->H + C3_TH - 1) / C3_TH;
+  s.in_scale = a->in_scale; s.in_shift = a->in_shift;
   const long ntiles = (long)s.B * s.tiles_h;
   if (ntiles > 0x7fffffffL) return SR_ERR_UNSUPPORTED;
+  if (a->in_scale) {
+    const int rc = c3_launch<false, true, true>(s, c3_grid(ntiles), (hipStream_t)stream);
+    if (rc != SR_OK) return rc;
+    SR_CHECK_LAUNCH();
+    return SR_OK;
+  }
   const bool aff = a->bias != nullptr || s.relu, st = a->stats != nullptr;
   const unsigned grid = c3_grid(ntiles);
   const int rc = aff ? (st ? c3_launch<true, true>(s, grid, (hipStream_t)stream) : c3_launch<true, false>(s, grid, (hipStream_t)stream))

@@ -79,6 +79,7 @@ int srx_stem_rows(const sr_conv_args* a);
 // direct 3x3 convolution of the 64-channel layer (c3d.hip); same convention
 int srx_c3d_conv(const sr_conv_args* a, void* stream);
 int srx_c3d_rows(const sr_conv_args* a);
+bool srx_c3d_in_affine_ok(const sr_conv_args* a);
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }

@@ -1383,7 +1383,7 @@ extern "C" int sr_conv_stats_rows(const sr_conv_args* a, int dtype) {
 extern "C" int sr_conv_in_affine_supported(const sr_conv_args* a, int dtype) {
   if (!a || a->B <= 0 || a->stride <= 0 || dtype != SR_BF16 || !use_v3() || a->stem) return 0;
   const long Ho = (a->H + 2 * a->pad - a->KH) / a->stride + 1, Wo = (a->W + 2 * a->pad - a->KW) / a->stride + 1;
-  return srx_conv1x1_in_affine_ok(a, (long)a->B * Ho * Wo) ? 1 : 0;
+  return (srx_conv1x1_in_affine_ok(a, (long)a->B * Ho * Wo) || srx_c3d_in_affine_ok(a)) ? 1 : 0;
 }
 
 extern "C" int sr_gemm_tile_cfg(int M, int N, int linear, int out_16bit) {
@@ -1456,7 +1456,8 @@ extern "C" int sr_conv2d(const sr_conv_args* a, int dtype, void* stream) {
   if (a->act != SR_ACT_NONE && a->act != SR_ACT_RELU) return SR_ERR_ARG;
   if (a->in_scale || a->in_shift) {       // input affine: only the weight-stationary expansion kernel applies it (never silently dropped)
     if (dtype != SR_BF16 || !use_v3() || a->stem) return SR_ERR_UNSUPPORTED;
-    return srx_conv1x1_expand(a, M, stream);
+    const int rc = srx_conv1x1_expand(a, M, stream);
+    return rc != SR_ERR_UNSUPPORTED ? rc : srx_c3d_conv(a, stream);
   }
   if (dtype == SR_BF16 && use_v3()) {     // output-heavy 1x1 convolutions: the kernel that overlaps K loop and epilogue (expand.hip)
     int rc = srx_conv1x1_expand(a, M, stream);

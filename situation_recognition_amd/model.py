@@ -242,6 +242,7 @@ class resnet(nn.Module):
         self._stats_epoch = 0          # bumped whenever a train-mode pass changed running statistics
         self._pending_tracked = 0      # num_batches_tracked increments not yet written to the buffers
         self._gram_stash = None        # (data_ptr, Gram partials) a fused BN-apply left for the expansion conv that follows
+        self._lazy_in = None           # (data_ptr, (scale, shift)): a RAW tensor whose BatchNorm + ReLU its consumer applies on load
         self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_counters())
         self.register_load_state_dict_post_hook(lambda m, incompatible: m._after_load())
 
@@ -365,11 +366,14 @@ class resnet(nn.Module):
                 scale, shift = ops.bn_finalize(st, x.shape[0] * Ho * Wo, gamma, beta, rm, rv, momentum, u.bn.eps, twin=tw)
             done()
             return ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=shift, escale=scale, res=res, relu=relu, in_affine=in_affine)
+        lazy_in, self._lazy_in = self._lazy_in, None
         if f8_in:
             wq, dq = u.fp8_pack(self.fp8_act_scale)
             y, st = ops.conv3x3_fp8(x, wq, dq, u.cout_p, stride=u.stride, want_stats=True)
         else:
-            y, st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, want_stats=True, stem_hw=stem_hw)
+            # (x may still be the RAW output of the unit in front: this conv then applies that unit's BatchNorm + ReLU on load)
+            aff = lazy_in[1] if lazy_in is not None and lazy_in[0] == x.data_ptr() else None
+            y, st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, want_stats=True, stem_hw=stem_hw, in_affine=aff)
         scale, shift = ops.bn_finalize(st, y.numel() // u.cout_p, gamma, beta, rm, rv, momentum, u.bn.eps, twin=tw)
         done()
         if quant_out:                                   # BatchNorm + ReLU + e4m3 in one sweep: the fp8 conv's input, half the bytes of bf16
@@ -386,6 +390,11 @@ class resnet(nn.Module):
                 self._gram_stash = (y.data_ptr(), ops.bn_gram(y.view(-1, u.cout_p), scale, shift), (scale, shift))
                 return y
             self._gram_stash = (y.data_ptr(), ops.bn_apply_gram(y.view(-1, u.cout_p), scale, shift), None)
+            return y
+        if (self.lazy_bn2 and then is not None and relu and res is None and then.k == 3 and y.dtype == torch.bfloat16 and not self.fp8
+                and ops.conv_in_affine_supported(y, then.cout_p, 3, then.stride, then.pad, res=None, relu=False, want_stats=True)):
+            # the consumer is the 3x3 that stages its whole input patch once (layer1): it normalises the raw tensor in LDS
+            self._lazy_in = (y.data_ptr(), (scale, shift))
             return y
         return ops.bn_apply(y, scale, shift, res=res, relu=relu, out=y)
 
@@ -508,7 +517,7 @@ class resnet(nn.Module):
                 y = a
                 for i, u in enumerate(convs[:-1]):
                     q8 = self.fp8 and len(convs) == 3 and i == 0 and convs[1].fp8_eligible()
-                    y = self._unit(y, u, train, momentum, relu=True, then=convs[i + 1] if i + 2 == len(convs) else None, twin=T(tconvs[i]),
+                    y = self._unit(y, u, train, momentum, relu=True, then=convs[i + 1], twin=T(tconvs[i]),
                                    quant_out=q8)
                 a = self._unit(y, convs[-1], train, momentum, relu=True, res=idn, twin=T(tconvs[-1]))
             feat = ops.avgpool(a)

@@ -91,10 +91,11 @@ def _conv_geometry(a, x, Cout, KH, stride, pad, res, relu):
     a.res, a.act = ptr(res), (ACT_RELU if relu else ACT_NONE)
 
 
-def conv_in_affine_supported(x, Cout, KH, stride, pad, res, relu):
-    """Will conv2d(x, ..., in_affine=...) be served (the expansion-conv kernel that normalises its input on load)?"""
+def conv_in_affine_supported(x, Cout, KH, stride, pad, res, relu, want_stats=False):
+    """Will conv2d(x, ..., in_affine=...) be served (the kernels that normalise their input on load: expansion 1x1, layer1's 3x3)?"""
     a = L.ConvArgs()
     _conv_geometry(a, x, Cout, KH, stride, pad, res, relu)
+    a.stats = x.data_ptr() if want_stats else None                 # (only tested against NULL)
     return lib().sr_conv_in_affine_supported(C.byref(a), dtype_code(x.dtype)) == 1
 
 

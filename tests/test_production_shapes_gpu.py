@@ -258,3 +258,23 @@ def test_expansion_conv_normalises_its_input_on_load(ops, Cin, Cout, H, B):
     assert torch.equal(pa[:, valid], pb[:, valid]) and torch.equal(keep, z2)
     with pytest.raises(Exception):                                     # stride 2: not the expansion form -> loud failure
         ops.conv2d(y2, pack_w(w), Cout, 1, 2, 0, in_affine=(sc2, sh2))
+
+
+@pytest.mark.parametrize("B,H", [(3, 56), (90, 56), (5, 24)])
+def test_direct_3x3_normalises_its_input_on_load(ops, B, H):
+    """bn1 -> relu -> conv2 of a layer1 bottleneck without the normalised tensor: the direct 3x3 kernel applies scale / shift + ReLU
+    to its input patch in LDS (pad pixels and the rows above / below the image stay zero: the convolution pads the NORMALISED
+    tensor).  Output and BatchNorm partial sums bit-identical to the same kernel on the tensor bn_apply wrote."""
+    Cc, W = 64, 56
+    y1 = rnd(B, H, W, Cc, seed=B + 3)
+    sc, sh = 0.5 + torch.rand(Cc, device="cuda"), 0.3 * torch.randn(Cc, device="cuda") + 0.2     # (relu(shift) != 0 on the pads if transformed)
+    w = rnd(Cc, Cc, 3, 3, seed=B + 4, scale=(Cc * 9) ** -0.5)
+    assert ops.conv_in_affine_supported(y1, Cc, 3, 1, 1, res=None, relu=False, want_stats=True)
+    lazy, st_l = ops.conv2d(y1, pack_w(w), Cc, 3, 1, 1, want_stats=True, in_affine=(sc, sh))
+    z1 = ops.bn_apply(y1, sc, sh, relu=True)
+    eager, st_e = ops.conv2d(z1, pack_w(w), Cc, 3, 1, 1, want_stats=True)
+    assert torch.equal(lazy, eager) and torch.equal(st_l, st_e)
+    ref = F.conv2d(F.relu(y1.float() * sc + sh).to(BF).float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1)
+    close(lazy.view(-1, Cc), ref.reshape(-1, Cc))
+    with pytest.raises(Exception):                                     # eval form (bias + ReLU): not served with an input affine
+        ops.conv2d(y1, pack_w(w), Cc, 3, 1, 1, bias=sh, relu=True, in_affine=(sc, sh))
