@@ -94,7 +94,10 @@ __device__ __forceinline__ void c3_body(const C3Args& p) {
   lstat[lane] = 0.f; lstat[64 + lane] = 0.f;
   if (threadIdx.x < 64) lbias[threadIdx.x] = p.bias ? p.bias[threadIdx.x] : 0.f;
   float* const inaff = reinterpret_cast<float*>(smem + C3_INAFF);
-  if (IN && threadIdx.x < 64) { inaff[threadIdx.x] = p.in_scale[threadIdx.x]; inaff[64 + threadIdx.x] = p.in_shift[threadIdx.x]; }
+  if (IN && threadIdx.x < 64) {              // (pair order inside every 8-channel chunk: sr_affine_relu_chunk)
+    const int ch = (threadIdx.x & ~7) | sr_pair_order(threadIdx.x & 7);
+    inaff[threadIdx.x] = p.in_scale[ch]; inaff[64 + threadIdx.x] = p.in_shift[ch];
+  }
 
   // ---- patch loader.  Piece q = i*4 + wave lands at LDS bytes q*1024 + lane*16 of the buffer: patch pixel pq = q*8 + lane/8, chunk
   // position lane%8, which holds data chunk (lane%8) ^ (pq & 7) of that pixel.  The per-lane source offsets are relative to
@@ -150,27 +153,18 @@ __device__ __forceinline__ void c3_body(const C3Args& p) {
       const unsigned ut0 = (unsigned)tile;
       const int y00 = (int)(ut0 - (ut0 / (unsigned)p.tiles_h) * (unsigned)p.tiles_h) * C3_TH;
       const int c8 = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
-      const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(inaff + c8), s1_ = *reinterpret_cast<const f32x4_t*>(inaff + c8 + 4);
-      const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(inaff + 64 + c8), h1 = *reinterpret_cast<const f32x4_t*>(inaff + 64 + c8 + 4);
-      const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1_[0], s1_[1], s1_[2], s1_[3]}, sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      const sr_f32x4 s0 = *reinterpret_cast<const sr_f32x4*>(inaff + c8), s1_ = *reinterpret_cast<const sr_f32x4*>(inaff + c8 + 4);
+      const sr_f32x4 h0 = *reinterpret_cast<const sr_f32x4*>(inaff + 64 + c8), h1 = *reinterpret_cast<const sr_f32x4*>(inaff + 64 + c8 + 4);
 #pragma unroll
       for (int i = 0; i < C3_NPW; ++i) {
         if (i * 4 + wave >= C3_NP) continue;
         const int row = y00 - 1 + ((vrel[i] >> 20) & 15);
         if (vrel[i] < 0 || row < 0 || row >= p.H) continue;
         char* const at = smem + buf * C3_PBUF + (i * 4 + wave) * 1024 + lane * 16;
-        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(at);
-        u32x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float lo = __builtin_fmaf(__uint_as_float(v[e] << 16), sc[2 * e], sh[2 * e]);
-          float hi = __builtin_fmaf(__uint_as_float(v[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]);
-          lo = lo > 0.f ? lo : 0.f;
-          hi = hi > 0.f ? hi : 0.f;
-          bf16_t pk[2] = {(bf16_t)lo, (bf16_t)hi};
-          o[e] = *reinterpret_cast<const unsigned*>(pk);
-        }
-        *reinterpret_cast<u32x4_t*>(at) = o;
+        const sr_u32x4 nv = sr_affine_relu_chunk(*reinterpret_cast<const sr_u32x4*>(at), s0, s1_, h0, h1);
+        // (written through inline asm: in front of an LDS store the compiler sees, it drains ALL vector-memory operations -- LDS-DMA
+        //  may alias -- which here would be the previous tile's 14 output stores, a full HBM write latency per tile)
+        asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)at), "v"(nv) : "memory");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }

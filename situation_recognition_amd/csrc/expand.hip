@@ -455,7 +455,10 @@ __device__ __forceinline__ void ws_body(const ExpArgs& p) {
 #pragma unroll
   for (int s = 0; s < D; ++s) issue(s, s);
   if (INAFF) {
-    for (int k = threadIdx.x; k < p.K; k += 512) { inaff[k] = p.in_scale[k]; inaff[p.K + k] = p.in_shift[k]; }
+    for (int k = threadIdx.x; k < p.K; k += 512) {       // (pair order inside every 8-channel chunk: sr_affine_relu_chunk)
+      const int ch = (k & ~7) | sr_pair_order(k & 7);
+      inaff[k] = p.in_scale[ch]; inaff[p.K + k] = p.in_shift[ch];
+    }
   }
   xwait_vm<0>();
   __syncthreads();
@@ -471,21 +474,9 @@ __device__ __forceinline__ void ws_body(const ExpArgs& p) {
       if (q >= PIECES) continue;
       const int c8 = (q / (TM / 16)) * 32 + ec;               // first of the chunk's 8 channels
       char* const at = smem + slot * ASLOT + a_dst[i] + lane * 16;
-      uint4 v = *reinterpret_cast<const uint4*>(at);
-      const float4 s0 = *reinterpret_cast<const float4*>(inaff + c8), s1 = *reinterpret_cast<const float4*>(inaff + c8 + 4);
-      const float4 h0 = *reinterpret_cast<const float4*>(inaff + p.K + c8), h1 = *reinterpret_cast<const float4*>(inaff + p.K + c8 + 4);
-      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-      unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float lo = __builtin_fmaf(__uint_as_float(w[e] << 16), sc[2 * e], sh[2 * e]);
-        float hi = __builtin_fmaf(__uint_as_float(w[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]);
-        lo = lo > 0.f ? lo : 0.f;
-        hi = hi > 0.f ? hi : 0.f;
-        bf16_t pk[2] = {(bf16_t)lo, (bf16_t)hi};
-        w[e] = *reinterpret_cast<const unsigned*>(pk);
-      }
-      *reinterpret_cast<uint4*>(at) = make_uint4(w[0], w[1], w[2], w[3]);
+      const sr_f32x4 s0 = *reinterpret_cast<const sr_f32x4*>(inaff + c8), s1 = *reinterpret_cast<const sr_f32x4*>(inaff + c8 + 4);
+      const sr_f32x4 h0 = *reinterpret_cast<const sr_f32x4*>(inaff + p.K + c8), h1 = *reinterpret_cast<const sr_f32x4*>(inaff + p.K + c8 + 4);
+      *reinterpret_cast<sr_u32x4*>(at) = sr_affine_relu_chunk(*reinterpret_cast<const sr_u32x4*>(at), s0, s1, h0, h1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };

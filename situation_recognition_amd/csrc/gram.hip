@@ -120,34 +120,22 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
   float* const lds_sc = reinterpret_cast<float*>(smem + NS * SLOT);
   const int c8 = ((tid % CPRW) ^ gram_swz<P>(tid / CPRW)) * 8;
   if (FUSE) {
-    if (tid < P) { lds_sc[tid] = p.scale[tid]; lds_sc[P + tid] = p.shift[tid]; }
+    if (tid < P) {                       // (pair order inside every 8-channel chunk: sr_affine_relu_chunk)
+      const int ch = (tid & ~7) | sr_pair_order(tid & 7);
+      lds_sc[tid] = p.scale[ch]; lds_sc[P + tid] = p.shift[ch];
+    }
     __syncthreads();
   }
   auto normalise = [&](int st) {
     char* img = smem + (st % NS) * SLOT + wave * 1024 + lane * 16;
     const long R = r0 + (long)st * SR;
-    float nsc[8], nsh[8];
-    {
-      const float4 s0 = *reinterpret_cast<const float4*>(lds_sc + c8), s1 = *reinterpret_cast<const float4*>(lds_sc + c8 + 4);
-      const float4 h0 = *reinterpret_cast<const float4*>(lds_sc + P + c8), h1 = *reinterpret_cast<const float4*>(lds_sc + P + c8 + 4);
-      nsc[0] = s0.x; nsc[1] = s0.y; nsc[2] = s0.z; nsc[3] = s0.w; nsc[4] = s1.x; nsc[5] = s1.y; nsc[6] = s1.z; nsc[7] = s1.w;
-      nsh[0] = h0.x; nsh[1] = h0.y; nsh[2] = h0.z; nsh[3] = h0.w; nsh[4] = h1.x; nsh[5] = h1.y; nsh[6] = h1.z; nsh[7] = h1.w;
-    }
+    const sr_f32x4 s0 = *reinterpret_cast<const sr_f32x4*>(lds_sc + c8), s1 = *reinterpret_cast<const sr_f32x4*>(lds_sc + c8 + 4);
+    const sr_f32x4 h0 = *reinterpret_cast<const sr_f32x4*>(lds_sc + P + c8), h1 = *reinterpret_cast<const sr_f32x4*>(lds_sc + P + c8 + 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bool ok = st < nst && R + src_row[j] < r1;
-      uint4 v = *reinterpret_cast<const uint4*>(img + j * 8192);
-      unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float lo = __builtin_fmaf(__uint_as_float(w[q] << 16), nsc[2 * q], nsh[2 * q]);
-        float hi = __builtin_fmaf(__uint_as_float(w[q] & 0xffff0000u), nsc[2 * q + 1], nsh[2 * q + 1]);
-        lo = lo > 0.f ? lo : 0.f;
-        hi = hi > 0.f ? hi : 0.f;
-        bf16_t pk[2] = {(bf16_t)lo, (bf16_t)hi};
-        w[q] = ok ? *reinterpret_cast<const unsigned*>(pk) : 0u;         // rows past the slice stay zero
-      }
-      v = make_uint4(w[0], w[1], w[2], w[3]);
+      const sr_u32x4 n = sr_affine_relu_chunk(*reinterpret_cast<const sr_u32x4*>(img + j * 8192), s0, s1, h0, h1);
+      const uint4 v = ok ? make_uint4(n[0], n[1], n[2], n[3]) : make_uint4(0u, 0u, 0u, 0u);       // rows past the slice stay zero
       *reinterpret_cast<uint4*>(img + j * 8192) = v;
       // KEEP: exactly one store per piece (rows past the slice: the trash page), so that the vmcnt arithmetic below holds
       if (KEEP) *reinterpret_cast<uint4*>(ok ? (char*)(const_cast<bf16_t*>(p.x) + R * p.ldx + src_off[j]) : (char*)p.trash + tid * 16) = v;
