@@ -283,13 +283,13 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const TI* __restrict__
   if (mirror && gpart && (row >> 4) > (col >> 4)) out[(long)col * symC + row] = v;
 }
 
-// One workgroup (1024 threads) per 8 output channels: s1 = w.cs, s2 = w G w in fp64, then the BatchNorm finalize of
-// bn_finalize_kernel (elementwise.hip) for those channels.  Thread (g, kk): rows l of sixteenth g of G, columns kk + 64u
+// One workgroup (512 threads) per 8 output channels: s1 = w.cs, s2 = w G w in fp64, then the BatchNorm finalize of
+// bn_finalize_kernel (elementwise.hip) for those channels.  Thread (g, kk): rows l of eighth g of G, columns kk + 64u
 // (u < 4) -- the w[l][0..7] a step needs are wave-uniform LDS reads (broadcasts), and those were what bounded the first
 // form of this kernel (one column per thread: 4 ds_read_b128 per 8 fp64 FMAs, 27 us per launch); four columns per thread
 // quarter them.  A thread's partial sum is multiplied by w[k] on the spot (the form is linear in it), so only the per-channel
 // totals are reduced across threads.
-__global__ __launch_bounds__(1024) void gram_project_kernel(const double* __restrict__ G, const double* __restrict__ cs,
+__global__ __launch_bounds__(512) void gram_project_kernel(const double* __restrict__ G, const double* __restrict__ cs,
                                                             const bf16_t* __restrict__ W, long ldw, int C, int N, double inv_count,
                                                             double unbias, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ rmean,
@@ -297,14 +297,14 @@ __global__ __launch_bounds__(1024) void gram_project_kernel(const double* __rest
                                                             float* __restrict__ scale, float* __restrict__ shift,
                                                             float* __restrict__ rmean2, float* __restrict__ rvar2, float momentum2) {
   __shared__ double wl[512][8];
-  __shared__ double red[2][16][8];
+  __shared__ double red[2][8][8];
   const int n0 = blockIdx.x * 8, tid = threadIdx.x;
-  for (int i = tid; i < C * 8; i += 1024) {
+  for (int i = tid; i < C * 8; i += 512) {
     const int l = i >> 3, j = i & 7;
     wl[l][j] = n0 + j < N ? (double)(float)W[(long)(n0 + j) * ldw + l] : 0.0;
   }
   __syncthreads();
-  const int g = tid >> 6, kk = tid & 63, lq = C >> 4;
+  const int g = tid >> 6, kk = tid & 63, lq = C >> 3;      // (512 threads: the 4 x 8 fp64 partial sums + 16 totals need ~130 registers)
   double s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(1024) void gram_project_kernel(const double* __rest
   if (tid >= 8 || n0 + tid >= N) return;
   const int c = n0 + tid;
   double t1 = 0.0, t2 = 0.0;
-  for (int w = 0; w < 16; ++w) { t1 += red[0][w][tid]; t2 += red[1][w][tid]; }
+  for (int w = 0; w < 8; ++w) { t1 += red[0][w][tid]; t2 += red[1][w][tid]; }
   const double mean = t1 * inv_count;
   double var = t2 * inv_count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -547,7 +547,7 @@ extern "C" int sr_bn_finalize_gram(const float* partials, int64_t npartials, int
   hipLaunchKernelGGL(gram_reduce_kernel<float>, dim3(gx, chunks), dim3(256), 0, st, partials, E, (int)npartials, per, E, stageA, symC, 0);
   hipLaunchKernelGGL(gram_reduce_kernel<double>, dim3(gx, 1), dim3(256), 0, st, (const double*)stageA, E, chunks, chunks, E, scratch, symC, 1);
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  hipLaunchKernelGGL(gram_project_kernel, dim3((N + 7) / 8), dim3(1024), 0, st, (const double*)scratch, (const double*)(scratch + (long)C * C),
+  hipLaunchKernelGGL(gram_project_kernel, dim3((N + 7) / 8), dim3(512), 0, st, (const double*)scratch, (const double*)(scratch + (long)C * C),
                      (const bf16_t*)w, (long)ldw, C, N, 1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps,
                      scale, shift, running_mean2, running_var2, momentum2);
   SR_CHECK_LAUNCH();
