@@ -42,6 +42,9 @@ extern "C" {
 #define SR_ACT_SIGMOID_MUL 4 /* C = s = sigmoid(v); C2 = s * aux1              (GRU reset: r, r*h)   */
 #define SR_ACT_TANH_BLEND 5  /* C2 = c = tanh(v); C = (1-aux2)*aux1 + aux2*c  (GRU candidate+blend) */
 
+/* Bumped on every incompatible change of a signature or struct below (2: sr_conv_args grew in_scale / in_shift, sr_bn_finalize*
+ * gained the twin buffers; 3: sr_conv_route, sr_comm_* / sr_allreduce_sum).  A binding must refuse a library whose version differs. */
+#define SR_ABI_VERSION 3
 int sr_abi_version(void);
 
 /* One (activation, weight) operand pair of a GEMM: contributes A[M,K] . W[N,K]^T. */
@@ -113,6 +116,18 @@ int sr_conv2d(const sr_conv_args* a, int dtype, void* stream);
  * ReLU, and the 64-channel 3x3 / stride 1 layer on 56-wide images in its train-mode form (statistics, no bias, no activation).
  * `res` and `stats` are only tested against NULL; no pointer is read. */
 int sr_conv_in_affine_supported(const sr_conv_args* a, int dtype);
+/* Which kernel sr_conv2d WOULD run this exact launch on (a dry run of its dispatch: same argument checks, nothing is launched,
+ * no pointer is dereferenced -- x / w / y must still be non-null and 16-byte aligned).  Returns a negative SR_ERR_* code the launch
+ * itself would return, or: 0 / 1 / 2 / 4 = the generic implicit-GEMM kernel on the tile shape sr_gemm_tile_cfg reports;
+ * SR_ROUTE_WS = conv1x1_ws_kernel (weight-stationary output-heavy 1x1),
+ * SR_ROUTE_C3D = conv3x3_c64_kernel (direct 3x3, 64 channels), SR_ROUTE_C3D128 = conv3x3_c128_kernel (direct 3x3, 128 channels),
+ * SR_ROUTE_STEM = stem_conv_kernel (direct 7x7/2 stem).
+ * Introspection for the parity tests: a test at a reduced batch asserts that it covered the kernel the benchmark batch runs. */
+#define SR_ROUTE_WS 16
+#define SR_ROUTE_C3D 18
+#define SR_ROUTE_STEM 19
+#define SR_ROUTE_C3D128 20
+int sr_conv_route(const sr_conv_args* a, int dtype);
 /* rows of `stats` this exact launch writes (the stem runs on a direct-convolution kernel with its own partial layout; every
  * other launch follows sr_gemm_stats_tiles(M, Cout)).  Fill the geometry fields of `a`; pointers are not read. */
 int sr_conv_stats_rows(const sr_conv_args* a, int dtype);
@@ -258,6 +273,23 @@ int sr_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, v
  * classifiers (model.py:105-111).  mask_out (uint8, nullable) receives keep(i).  The same call with
  * x = upstream gradient is the backward. */
 int sr_dropout_half(const void* x, void* y, uint8_t* mask_out, int64_t n, uint64_t seed, int dtype, void* stream);
+
+/* ---- Data-parallel gradient exchange: RCCL all-reduce over xGMI (one process per GPU).
+ * Replaces nn.DataParallel (reference sr.py:467-470), whose backward (sr.py:79) sums the replicas' gradients onto GPU 0 with
+ * reduce_add_coalesced: here every rank holds its trainable gradients in one flat buffer and sums it in place across the ranks.
+ *   sr_comm_unique_id  rank 0 fills SR_COMM_ID_BYTES (an ncclUniqueId) and hands them to the other ranks by any host-side channel
+ *   sr_comm_init       collective over `world` processes, each with its own current HIP device; *comm_out = the communicator
+ *   sr_comm_world      number of ranks of a communicator (>= 1) or a negative error
+ *   sr_allreduce_sum   buf[i] <- sum over ranks of buf[i], in place, `count` elements of `dtype` (SR_F32 / SR_BF16), enqueued on
+ *                      `stream`; every rank must issue the same sequence of calls
+ *   sr_comm_destroy    releases the communicator
+ * RCCL itself is loaded on first use (librccl.so.1); SR_ERR_UNSUPPORTED when it cannot be found. */
+#define SR_COMM_ID_BYTES 128
+int sr_comm_unique_id(void* id_out);
+int sr_comm_init(const void* id_in, int rank, int world, void** comm_out);
+int sr_comm_world(void* comm);
+int sr_allreduce_sum(void* comm, void* buf, int64_t count, int dtype, void* stream);
+int sr_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

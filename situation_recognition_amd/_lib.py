@@ -11,7 +11,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SR_LIB_PATH") or os.path.join(_HERE, "libsrhip.so")   # SR_LIB_PATH: diagnostic builds only
 
+ABI_VERSION = 3                  # include/srhip.h: SR_ABI_VERSION
 SR_F32, SR_BF16 = 0, 1
+ROUTE_WS, ROUTE_C3D, ROUTE_STEM, ROUTE_C3D128 = 16, 18, 19, 20     # sr_conv_route codes
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SIGMOID_MUL, ACT_TANH_BLEND = range(6)
 _ERR = {-1: "SR_ERR_ARG (bad shape/alignment/null pointer)", -2: "SR_ERR_DTYPE", -3: "SR_ERR_LAUNCH",
         -4: "SR_ERR_UNSUPPORTED"}
@@ -51,6 +53,7 @@ SIGNATURES = {
     "sr_debug_stamps": [_P, _I],
     "sr_conv2d": [C.POINTER(ConvArgs), _I, _P],
     "sr_conv_stats_rows": [C.POINTER(ConvArgs), _I],
+    "sr_conv_route": [C.POINTER(ConvArgs), _I],
     "sr_conv_in_affine_supported": [C.POINTER(ConvArgs), _I],
     "sr_stem_bn_relu_maxpool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sr_stem_prep": [_P, _P, _I, _I, _I, _I, _P],
@@ -79,6 +82,11 @@ SIGNATURES = {
     "sr_cast_pad": [_P, _L, _P, _L, _L, _L, _L, _I, _I, _P],
     "sr_cast": [_P, _P, _L, _I, _I, _P],
     "sr_dropout_half": [_P, _P, _P, _L, _U64, _I, _P],
+    "sr_comm_unique_id": [_P],
+    "sr_comm_init": [_P, _I, _I, C.POINTER(C.c_void_p)],
+    "sr_comm_world": [_P],
+    "sr_allreduce_sum": [_P, _P, _L, _I, _P],
+    "sr_comm_destroy": [_P],
 }
 
 _lib = None
@@ -95,6 +103,9 @@ def lib():
             fn = getattr(l, name)          # AttributeError if the symbol is missing
             fn.argtypes = argtypes
             fn.restype = C.c_int
+        if l.sr_abi_version() != ABI_VERSION:    # a stale .so would read a pointer where this binding passes a stream
+            raise SrError("libsrhip.so at %s has ABI version %d, this binding expects %d: rebuild it "
+                          "(python situation_recognition_amd/csrc/build.py --force)" % (LIB_PATH, l.sr_abi_version(), ABI_VERSION))
         _lib = l
     return _lib
 

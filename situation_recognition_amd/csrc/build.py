@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libsrhip.so")
 OBJ = os.path.join(HERE, "_obj")
-SOURCES = ["gemm.hip", "gram.hip", "elementwise.hip", "ggnn.hip", "expand.hip", "fp8.hip", "stem.hip", "c3d.hip"]
+SOURCES = ["gemm.hip", "gram.hip", "elementwise.hip", "ggnn.hip", "expand.hip", "fp8.hip", "stem.hip", "c3d.hip", "comm.hip"]
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(PKG), "include", "srhip.h")]
 # -pragma-unroll-threshold: the GEMM epilogues are fully unrolled over 32 accumulator fragments; LLVM's default
 # threshold (16K) silently downgrades "#pragma unroll" to a partial unroll, which makes the accumulator index dynamic and
@@ -56,16 +56,16 @@ def build(force=False, verbose=True):
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(OUT, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"])
     return OUT
 
 
 def build_stamps():
-    """Diagnostic library with in-kernel cycle stamps in expand.hip (-DXSTAMPS) and gemm.hip (-DSR_STAMPS, read back with
+    """Diagnostic library with in-kernel cycle stamps in gemm.hip (-DSR_STAMPS, read back with
     sr_debug_stamps under SR_GEMM_DEBUG=4): libsrhip_stamps.so; select it with SR_LIB_PATH."""
     build(verbose=False)
     hipcc = _hipcc()
-    stamped = {"expand.hip": "-DXSTAMPS", "gemm.hip": "-DSR_STAMPS"}
+    stamped = {"gemm.hip": "-DSR_STAMPS"}
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s not in stamped]
     jobs = []
     for src, flag in stamped.items():
@@ -75,7 +75,7 @@ def build_stamps():
     with ThreadPoolExecutor(max_workers=2) as ex:
         list(ex.map(lambda c: subprocess.run(c, check=True), jobs))
     out = os.path.join(PKG, "libsrhip_stamps.so")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"], check=True)
     return out
 
 

@@ -364,6 +364,7 @@ int srx_c3d_conv(const sr_conv_args* a, void* stream) {
   s.in_scale = a->in_scale; s.in_shift = a->in_shift;
   const long ntiles = (long)s.B * s.tiles_h;
   if (ntiles > 0x7fffffffL) return SR_ERR_UNSUPPORTED;
+  SR_ROUTE(SR_ROUTE_C3D);
   if (a->in_scale) {
     const int rc = c3_launch<false, true, true>(s, c3_grid(ntiles), (hipStream_t)stream);
     if (rc != SR_OK) return rc;

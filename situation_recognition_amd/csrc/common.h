@@ -99,6 +99,12 @@ __device__ __forceinline__ sr_u32x4 sr_affine_relu_chunk(sr_u32x4 v, sr_f32x4 s0
   return o;
 }
 
+// sr_conv_route (gemm.hip): a dry run of sr_conv2d's dispatch.  While sr_route_probe is set, every launch site records the
+// code of the kernel it WOULD launch and returns instead of launching (codes: include/srhip.h, SR_ROUTE_*).
+extern thread_local int sr_route_probe;
+extern thread_local int sr_route_code;
+#define SR_ROUTE(code) do { if (sr_route_probe) { sr_route_code = (code); return SR_OK; } } while (0)
+
 // expand.hip: the output-heavy 1x1 convolutions (internal hand-over from sr_conv2d; SR_ERR_UNSUPPORTED = not one of its shapes)
 int srx_conv1x1_expand(const sr_conv_args* a, long M, void* stream);
 bool srx_conv1x1_in_affine_ok(const sr_conv_args* a, long M);

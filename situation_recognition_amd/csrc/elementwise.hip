@@ -391,7 +391,7 @@ __global__ void dropout_half_kernel(const T* __restrict__ x, T* __restrict__ y, 
   else if ((dtype) == SR_BF16) { using T = bf16_t; EXPR; } \
   else return SR_ERR_DTYPE;
 
-extern "C" int sr_abi_version(void) { return 1; }
+extern "C" int sr_abi_version(void) { return SR_ABI_VERSION; }
 
 extern "C" int sr_stem_prep(const float* img, void* out, int B, int H, int W, int dtype, void* stream) {
   if (!img || !out || B <= 0 || H <= 0 || W <= 0) return SR_ERR_ARG;

@@ -1311,6 +1311,7 @@ int launch(const KArgs& k, hipStream_t st) {
   // N not a multiple of 8: 16-bit outputs (see the staged store of the v3 epilogue) and launches with statistics
   // (sr_gemm_stats_tiles does not know the output type) take the v2 kernels
   const bool ragged16 = (k.N & 7) != 0 && (sizeof(TO) == 2 || k.stats != nullptr);
+  SR_ROUTE(ragged16 ? 0 : v3_cfg(k.M, k.N, linear));
   switch (ragged16 ? 0 : v3_cfg(k.M, k.N, linear)) {
     case 4: return launch_v3<T, TO, 4>(k, st);
     case 2: return launch_v3<T, TO, 2>(k, st);
@@ -1329,9 +1330,11 @@ inline int debug_flags() {
 int dispatch(const KArgs& k_in, int dtype, int out_f32, hipStream_t st) {
   KArgs k = k_in;
   k.debug = debug_flags();
-  k.zero_page = SR_DEVICE_SYMBOL(g_zero_page);       // (per device: see common.h)
-  k.trash_page = SR_DEVICE_SYMBOL(g_trash_page);
-  if (!k.zero_page || !k.trash_page) return SR_ERR_LAUNCH;
+  if (!sr_route_probe) {
+    k.zero_page = SR_DEVICE_SYMBOL(g_zero_page);       // (per device: see common.h)
+    k.trash_page = SR_DEVICE_SYMBOL(g_trash_page);
+    if (!k.zero_page || !k.trash_page) return SR_ERR_LAUNCH;
+  }
   if (dtype == SR_F32) return launch<float, float>(k, st);
   if (dtype == SR_BF16) return out_f32 ? launch<bf16_t, float>(k, st) : launch<bf16_t, bf16_t>(k, st);
   return SR_ERR_DTYPE;
@@ -1384,6 +1387,18 @@ extern "C" int sr_conv_in_affine_supported(const sr_conv_args* a, int dtype) {
   if (!a || a->B <= 0 || a->stride <= 0 || dtype != SR_BF16 || !use_v3() || a->stem) return 0;
   const long Ho = (a->H + 2 * a->pad - a->KH) / a->stride + 1, Wo = (a->W + 2 * a->pad - a->KW) / a->stride + 1;
   return (srx_conv1x1_in_affine_ok(a, (long)a->B * Ho * Wo) || srx_c3d_in_affine_ok(a)) ? 1 : 0;
+}
+
+thread_local int sr_route_probe = 0;
+thread_local int sr_route_code = -1;
+
+extern "C" int sr_conv_route(const sr_conv_args* a, int dtype) {
+  sr_route_probe = 1;
+  sr_route_code = -1;
+  const int rc = sr_conv2d(a, dtype, nullptr);
+  sr_route_probe = 0;
+  if (rc != SR_OK) return rc;
+  return sr_route_code >= 0 ? sr_route_code : SR_ERR_LAUNCH;
 }
 
 extern "C" int sr_gemm_tile_cfg(int M, int N, int linear, int out_16bit) {

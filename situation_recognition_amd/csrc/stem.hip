@@ -384,6 +384,7 @@ int srx_stem_conv(const sr_conv_args* a, void* stream) {
   s.tiles_h = (Ho + 15) / 16; s.tiles_w = (Wo + 15) / 16;
   const long ntiles = (long)s.B * s.tiles_h * s.tiles_w;
   if (ntiles > 0x7fffffffL) return SR_ERR_UNSUPPORTED;
+  SR_ROUTE(SR_ROUTE_STEM);
   constexpr int LDS = 2 * PBUF + 8 * 2048 + 256;
   if (!sr_set_dynamic_lds_tagged<StemTag>(reinterpret_cast<const void*>(&stem_conv_kernel), LDS)) return SR_ERR_LAUNCH;
   hipLaunchKernelGGL(stem_conv_kernel, dim3(stem_grid(ntiles)), dim3(512), LDS, (hipStream_t)stream, s);

@@ -239,6 +239,7 @@ class resnet(nn.Module):
         self.graph_train = False       # ... train-mode passes too (small per-GPU batches: ~900 launches of 10-200 us, 3 us apart)
         self._capturing = False
         self._graphs = {}
+        self.graph_replays = 0         # passes served by a graph launch (tests assert that the replay branch really ran)
         self._stats_epoch = 0          # bumped whenever a train-mode pass changed running statistics
         self._pending_tracked = 0      # num_batches_tracked increments not yet written to the buffers
         self._gram_stash = None        # (data_ptr, Gram partials) a fused BN-apply left for the expansion conv that follows
@@ -266,11 +267,14 @@ class resnet(nn.Module):
         self._graphs.clear()
         return super()._apply(fn, *a, **kw)
 
-    def _weights_signature(self):
-        """Changes whenever any backbone parameter or buffer is modified in place or replaced (sum of tensor versions +
-        storage addresses): the key of the captured graphs, whose folded weight packs are baked in."""
+    def _weights_signature(self, buffers=True):
+        """Changes whenever any backbone parameter (or, with `buffers`, BatchNorm buffer) is modified in place or replaced (sum
+        of tensor versions + storage addresses): the key of the captured graphs.  Eval-mode graphs bake in weight packs folded
+        with the running statistics, so the buffers are part of their key; train-mode graphs read only the parameters and UPDATE
+        the buffers themselves (a channel-padded net even through `copy_`, which bumps their versions every pass), so theirs is
+        keyed on the parameters alone."""
         v = 0
-        for t in itertools.chain(self.model.parameters(), self.model.buffers()):
+        for t in itertools.chain(self.model.parameters(), self.model.buffers() if buffers else ()):
             v += t._version + (t.data_ptr() & 0xffffffff)
         return v
 
@@ -398,6 +402,51 @@ class resnet(nn.Module):
             return y
         return ops.bn_apply(y, scale, shift, res=res, relu=relu, out=y)
 
+    def _run_block(self, a, bi, train, momentum, tblock=None, T=lambda tu: None):
+        """One residual block on the NHWC activation `a` (torchvision Bottleneck / BasicBlock: conv-BN-ReLU chain, optional
+        1x1 downsample of the identity, add, ReLU).  `tblock`: the same block of a weight-identical twin backbone."""
+        convs, ds = self._plan()[1][bi]
+        tconvs, tds = tblock if tblock is not None else ([None] * len(convs), None)
+        idn = a if ds is None else self._unit(a, ds, train, momentum, relu=False, twin=T(tds))
+        y = a
+        for i, u in enumerate(convs[:-1]):
+            q8 = self.fp8 and len(convs) == 3 and i == 0 and convs[1].fp8_eligible()
+            y = self._unit(y, u, train, momentum, relu=True, then=convs[i + 1], twin=T(tconvs[i]), quant_out=q8)
+        return self._unit(y, convs[-1], train, momentum, relu=True, res=idn, twin=T(tconvs[-1]))
+
+    def num_blocks(self):
+        return len(self._plan()[1])
+
+    def stem_forward(self, x):
+        """conv1 -> bn1 -> relu -> maxpool alone (the teacher-forced per-block parity tests feed every block the oracle's input):
+        image batch -> NHWC activation [B, H/4, W/4, 64]."""
+        stem = self._plan()[0]
+        m = self.model.bn1.momentum if self.model.bn1.momentum is not None else 0.1
+        with torch.no_grad():
+            xp, H, W = self.prepare_input(x)
+            a = self._unit(xp, stem, self.training, m, relu=True, stem_hw=(H, W), pool_after=True)
+        if self.training:
+            self._stats_epoch += 1
+            self.model.bn1.num_batches_tracked += 1
+        return a
+
+    def block_forward(self, a, bi):
+        """Residual block `bi` (0 .. num_blocks()-1, torchvision order layer1.0 ... layer4.2) alone, through exactly the launches
+        the full pass makes for it: NHWC activation in the backbone's dtype -> NHWC activation.  Train mode updates that block's
+        running statistics once."""
+        if not a.is_cuda or a.dtype != self.dtype or a.dim() != 4:
+            raise SrError("block_forward expects an NHWC activation in the backbone's dtype on the GPU")
+        m = self.model.bn1.momentum if self.model.bn1.momentum is not None else 0.1
+        self._gram_stash = self._lazy_in = None
+        with torch.no_grad():
+            out = self._run_block(a.contiguous(), bi, self.training, m)
+        if self.training:
+            self._stats_epoch += 1
+            convs, ds = self._plan()[1][bi]
+            for u in convs + ([ds] if ds is not None else []):
+                u.bn.num_batches_tracked += 1
+        return out
+
     def forward(self, x, bn_updates=1, twin=None, twin_updates=0, prepped=None):
         """`bn_updates`=2 gives the running-statistics state of two consecutive train-mode passes over the
         same batch in one pass (FCGGNN.forward runs convnet_nouns twice on the same images, model.py:176-178).
@@ -444,6 +493,7 @@ class resnet(nn.Module):
         g, static_in, static_out = hit
         static_in.copy_(x)
         g.replay()
+        self.graph_replays += 1
         return static_out.clone()
 
     def _graph_forward_train(self, x, bn_updates):
@@ -452,7 +502,8 @@ class resnet(nn.Module):
         temporaries, so the captured graph IS the pass; what stays in Python is the bookkeeping of num_batches_tracked.  The first
         call with a given shape runs eagerly (that is the call's result) and only then captures -- capturing executes nothing, so
         the running statistics are not updated twice."""
-        key = ("train", tuple(x.shape), x.dtype, self.dtype, self._weights_signature(), bn_updates)
+        key = ("train", tuple(x.shape), x.dtype, self.dtype, self._weights_signature(buffers=False),
+               tuple(t.data_ptr() for t in self.model.buffers()), bn_updates)
         hit = self._graphs.get(key)
         if hit is None:
             out = self._forward_impl(x, bn_updates)
@@ -472,6 +523,7 @@ class resnet(nn.Module):
         g, static_in, static_out = hit
         static_in.copy_(x)
         g.replay()
+        self.graph_replays += 1
         self._stats_epoch += 1
         self._pending_tracked += bn_updates
         return static_out.clone()
@@ -511,15 +563,8 @@ class resnet(nn.Module):
         with torch.no_grad():
             xp, H, W = prepped if prepped is not None else self.prepare_input(x)
             a = self._unit(xp, stem, train, momentum, relu=True, stem_hw=(H, W), pool_after=True, twin=T(tstem))
-            for bi, (convs, ds) in enumerate(blocks):
-                tconvs, tds = tblocks[bi] if twin is not None else ([None] * len(convs), None)
-                idn = a if ds is None else self._unit(a, ds, train, momentum, relu=False, twin=T(tds))
-                y = a
-                for i, u in enumerate(convs[:-1]):
-                    q8 = self.fp8 and len(convs) == 3 and i == 0 and convs[1].fp8_eligible()
-                    y = self._unit(y, u, train, momentum, relu=True, then=convs[i + 1], twin=T(tconvs[i]),
-                                   quant_out=q8)
-                a = self._unit(y, convs[-1], train, momentum, relu=True, res=idn, twin=T(tconvs[-1]))
+            for bi in range(len(blocks)):
+                a = self._run_block(a, bi, train, momentum, tblocks[bi] if twin is not None else None, T)
             feat = ops.avgpool(a)
         if train and not self._capturing:
             self._stats_epoch += 1
@@ -834,7 +879,8 @@ class FCGGNN(nn.Module):
     def forward(self, img, gt_verb):                                                    # model.py:172-180
         batch_size = img.size(0)
         overlap = self.overlap_backbones if self.overlap_backbones is not None else True
-        if self.share_identical_backbones and self.training and img.is_cuda and self.convnet_verbs.weights_equal(self.convnet_nouns):
+        if (self.share_identical_backbones and self.training and self.convnet_verbs.training and self.convnet_nouns.training
+                and img.is_cuda and self.convnet_verbs.weights_equal(self.convnet_nouns)):
             # Both backbones still hold the SAME frozen weights (what the reference's two `pretrained=True` loads give) and
             # train-mode BatchNorm ignores the running statistics: their features are identical, so ONE pass serves the verb
             # path and both noun branches.  The noun backbone's BatchNorm buffers still receive their two updates.

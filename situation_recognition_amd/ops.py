@@ -99,6 +99,25 @@ def conv_in_affine_supported(x, Cout, KH, stride, pad, res, relu, want_stats=Fal
     return lib().sr_conv_in_affine_supported(C.byref(a), dtype_code(x.dtype)) == 1
 
 
+def conv_route(B, H, W_, Cin, Cout, KH, stride, pad, dtype=torch.bfloat16, res=False, relu=False, bias=False, escale=False,
+               want_stats=False, stats_only=False, in_affine=False, stem=False):
+    """The kernel sr_conv2d runs this launch on (sr_conv_route: 0/1/2/4 = generic implicit GEMM on that tile shape, L.ROUTE_* = the
+    specialised kernels).  Geometry only: no tensor is needed, nothing is launched."""
+    a = L.ConvArgs()
+    dummy = 0x1000                                                   # non-null, 16-byte aligned; never dereferenced by the dry run
+    a.x, a.w, a.y = dummy, dummy, dummy
+    a.B, a.H, a.W, a.Cin, a.Cout = B, H, W_, Cin, Cout
+    a.KH, a.KW, a.stride, a.pad, a.stem = KH, KH, stride, pad, int(stem)
+    a.res, a.act = (dummy if res else None), (ACT_RELU if relu else ACT_NONE)
+    a.bias, a.escale = (dummy if bias else None), (dummy if escale else None)
+    a.stats, a.no_store = (dummy if (want_stats or stats_only) else None), int(stats_only)
+    if in_affine:
+        a.in_scale = a.in_shift = dummy
+    rc = lib().sr_conv_route(C.byref(a), dtype_code(dtype))
+    check(min(rc, 0), "sr_conv_route")
+    return rc
+
+
 def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_stats=False, stem_hw=None, escale=None,
            stats_only=False, out=None, in_affine=None):
     """x: NHWC [B,H,W,Cin] (or, with stem_hw=(H,W), the padded NHWC4 image from stem_prep);

@@ -65,6 +65,64 @@ def global_batch_loss(model, pred_verb, pred_nouns, gt_verb, gt_nouns, group=Non
     return vl + nl, vl, nl, (b_glob, n_glob)
 
 
+class HipComm:
+    """RCCL communicator owned through the C ABI (`sr_comm_*` / `sr_allreduce_sum`, include/srhip.h): the exchange step of the
+    data-parallel path without torch.distributed's collectives.  The ncclUniqueId travels from rank 0 to the others over the
+    already-initialised torch.distributed process group (host-side rendezvous only); every rank must have selected its GPU.
+    World size 1 needs no process group."""
+
+    def __init__(self, rank=None, world=None, group=None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib, C
+        self.world = _world(group) if world is None else world
+        self.rank = (dist.get_rank(group) if dist.is_initialized() else 0) if rank is None else rank
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            _lib.check(_lib.lib().sr_comm_unique_id(ident), "sr_comm_unique_id")
+        if self.world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        handle = C.c_void_p()
+        _lib.check(_lib.lib().sr_comm_init(ident, self.rank, self.world, C.byref(handle)), "sr_comm_init")
+        self._h = handle
+        self.stream = torch.cuda.Stream()          # the collective's own stream: it runs beside the rest of the backward
+
+    def all_reduce_sum_(self, t, stream=None):
+        """In-place sum of the contiguous fp32 / bf16 CUDA tensor `t` over the ranks, ordered after the work already enqueued on
+        the current stream; returns an event the consumer waits on."""
+        if not t.is_cuda or not t.is_contiguous():
+            raise self._lib.SrError("all_reduce_sum_: contiguous CUDA tensor expected")
+        s = stream or self.stream
+        s.wait_stream(torch.cuda.current_stream())
+        self._lib.check(self._lib.lib().sr_allreduce_sum(self._h, t.data_ptr(), t.numel(), self._lib.dtype_code(t.dtype), s.cuda_stream),
+                        "sr_allreduce_sum")
+        t.record_stream(s)
+        ev = torch.cuda.Event()
+        ev.record(s)
+        return ev
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._lib.lib().sr_comm_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _EventWork:
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class GradBucket:
     """Flat fp32 buffer over the trainable parameters whose slices ARE the parameters' `.grad` tensors, cut into buckets.
 
@@ -78,9 +136,11 @@ class GradBucket:
     `finish()` sees what the reference's single replica sees (sr.py:79-81).
     """
 
-    def __init__(self, params, group=None, average=False, min_bucket_bytes=4 << 20):
+    def __init__(self, params, group=None, average=False, min_bucket_bytes=4 << 20, comm=None):
+        """`comm`: a HipComm -- the buckets are then summed by `sr_allreduce_sum` (RCCL through the C ABI) instead of
+        torch.distributed's all_reduce (which is RCCL as well under the "nccl" backend, gloo in the CPU tests)."""
         self.params = [p for p in params if p.requires_grad]
-        self.group, self.average = group, average
+        self.group, self.average, self.comm = group, average, comm
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -107,9 +167,22 @@ class GradBucket:
         self._pending = [len(b) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._hooks = []
         for p in self.params:
             p.grad = self.views[self._index[id(p)]]
-            p.register_post_accumulate_grad_hook(self._on_grad)
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def close(self):
+        """Detach from the parameters: a second GradBucket over the same parameters must not find this one's hooks alive."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def nbytes(self):
@@ -130,8 +203,11 @@ class GradBucket:
 
     def _launch(self, b):
         self._launched[b] = True
-        if _world(self.group) > 1:
-            lo, hi = self._span(b)
+        lo, hi = self._span(b)
+        if self.comm is not None:
+            if self.comm.world > 1:
+                self._works.append(_EventWork(self.comm.all_reduce_sum_(self.flat[lo:hi])))
+        elif _world(self.group) > 1:
             self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_grad(self, p):
@@ -140,8 +216,12 @@ class GradBucket:
             self.views[i].copy_(p.grad)
             p.grad = self.views[i]
         b = self._bucket_of[i]
+        if self._launched[b]:
+            # a second backward() between two zero() calls: its gradients would miss the all-reduce that has already run
+            raise RuntimeError("GradBucket: a gradient arrived for a bucket whose all-reduce was already launched -- "
+                               "call zero() before every backward (gradient accumulation over several backwards is not supported)")
         self._pending[b] -= 1
-        if self._pending[b] == 0 and not self._launched[b]:
+        if self._pending[b] == 0:
             self._launch(b)
 
     def finish(self):
@@ -151,8 +231,9 @@ class GradBucket:
         for w in self._works:
             w.wait()
         self._works = []
-        if self.average and _world(self.group) > 1:
-            self.flat.div_(_world(self.group))
+        n = self.comm.world if self.comm is not None else _world(self.group)
+        if self.average and n > 1:
+            self.flat.div_(n)
 
     def reduce(self):
         """One-call form for code that does not use the hooks' overlap: everything not yet launched goes now."""

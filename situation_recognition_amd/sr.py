@@ -52,9 +52,12 @@ class _EvalShard(torch.utils.data.Sampler):
 
 
 def eval(model, loader, encoder, logging=False):                         # noqa: A001  (reference name, sr.py:165)
-    """reference sr.py:165-232.  With several ranks each one scores its shard of the set and the score-card sums, sample
-    counts and loss sums are all-reduced, so every rank returns (and rank 0 prints / checkpoints) the metric of the WHOLE
-    set, as the reference's single process does."""
+    """reference sr.py:165-232.  With several ranks each one scores its shard of the set and the score-card sums and sample
+    counts are all-reduced, so every rank returns (and rank 0 prints / checkpoints) the scorer metrics of the WHOLE set, exactly
+    as the reference's single process does.  The three validation LOSSES are, as in the reference (sr.py:199-214), the mean over
+    batches of per-batch means -- here over every rank's batches: the same estimator on a different partition of the set into
+    batches (batch_size // world per rank, ragged last batches), so their last digits depend on the world size, as the
+    reference's depend on its batch size."""
     model.eval()
     dev = next(model.parameters()).device
     top1, top5 = imsitu_scorer(encoder, 1, 3), imsitu_scorer(encoder, 5, 3)

@@ -3,9 +3,11 @@
 config 2  ResNet-50 + 6-role GGNN T=4, batch 256, fp32: eval-mode logits of the first 8 images against the CPU oracle
           (<= 1e-3, the north_star tolerance), and -- size-independent property -- every image's logits in the batch-256
           run equal its logits when run in a batch of 8 (eval-mode BatchNorm makes images independent).
-config 3  ResNet-152 + 6-role GGNN T=5, bf16, imSitu-sized vocabulary, batch 6144 (the benchmark's per-GPU size): same slicing
-          property, eight images against the fp32 oracle, plus train-mode invariants (finite losses, running statistics move,
-          gradients reach every trainable parameter).
+config 3  ResNet-152 + 6-role GGNN T=5, bf16, imSitu-sized vocabulary, batch 6144 (the benchmark's per-GPU size): 1024-image slices
+          equal the full run bit for bit, train-mode invariants (finite losses, running statistics move, gradients reach every
+          trainable parameter); the end-to-end distance from the fp32 oracle is REPORTED (bf16 parity is gated per block in
+          tests/test_blocks_teacher_forced_gpu.py).
+config 5  ResNet-152 with e4m3 3x3 convolutions + 6-role GGNN T=8, batch 8192: launch count, slicing property, one training step.
 """
 import pytest
 import torch
@@ -67,11 +69,27 @@ def _device_images(B, seed):
     return img
 
 
+def _slices_equal_full(net, img, verb, full, starts, n):
+    """Size-independent property of eval mode: BatchNorm uses running statistics, so images are independent, and a slice of
+    `n` images that is dispatched to the same kernels as the full batch (n * 49 >= 32768 rows keeps even layer4 on the
+    weight-stationary / 256-wide kernels; the K order of an output element does not depend on the tile it sits in) must
+    reproduce the full run's logits BIT FOR BIT."""
+    for lo in starts:
+        with torch.no_grad():
+            part = net(img[lo:lo + n].contiguous(), verb[lo:lo + n].contiguous())
+        for k, (f, p) in enumerate(zip(full, part)):
+            assert torch.equal(f[lo:lo + n], p), "output %d of images %d..%d differs between the full batch and the slice" % (k, lo, lo + n)
+
+
 def test_config3_resnet152_bf16_batch6144_slicing_oracle_and_train_invariants():
     """BASELINE config 3 at its FULL size (per-GPU batch 6144: the largest activation is 9.9 GB, row counts up to 77 M --
-    the >2^31-byte regime): eval-mode logits of slices of the batch equal the same images run alone (eval BatchNorm
-    makes images independent; same K order per output element whatever the batch), eight of them are compared with the fp32
-    CPU oracle, and one train-mode step keeps the invariants of reference model.py:172-180 / sr.py:63-83."""
+    the >2^31-byte regime).  What is ASSERTED: finite logits; 1024-image slices of the batch reproduce the full run bit for bit
+    (eval-mode images are independent); one train-mode step keeps the invariants of reference model.py:172-180 / sr.py:63-83.
+    What is REPORTED, not gated: the distance of eight images' features / logits from the fp32 oracle.  A randomly initialised
+    152-layer net amplifies the bf16 rounding of every activation (measured in round 2: 0.20 relative L2 on pooled features, 0.06
+    absolute on logits whose range is 0.26), so an end-to-end tolerance would have to be fitted to the measurement and would
+    let a wrong layer pass.  The bf16 parity claim rests on tests/test_blocks_teacher_forced_gpu.py (every block against the
+    oracle on the oracle's own input, production-size launches, 1.2e-2) and tests/test_production_shapes_gpu.py (every kernel)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     g = torch.Generator().manual_seed(6)
@@ -82,39 +100,20 @@ def test_config3_resnet152_bf16_batch6144_slicing_oracle_and_train_invariants():
     net.eval(); ora.eval()
     with torch.no_grad():
         full = net(img, verb)
-        parts = {lo: net(img[lo:lo + 32].contiguous(), verb[lo:lo + 32].contiguous()) for lo in (0, 3040, B - 32)}
         want = ora(img[3040:3048].float().cpu(), verb[3040:3048].cpu())
     for f in full:
         assert torch.isfinite(f).all()
-    # A 32-image launch runs other kernels than the 6144-image one (narrow tiles; the expansion-conv kernel of csrc/expand.hip,
-    # which rounds to bf16 once instead of twice, only serves launches of >= 32 768 rows), so the two differ by bf16 rounding
-    # noise amplified through 152 layers -- the same bound as against the fp32 oracle below, not bit equality.
-    # (pred_nouns is conditioned on argmax(pred_verb): only images whose predicted verb agrees between the two runs are compared)
-    for lo, part in parts.items():
-        same = (full[0][lo:lo + 32].float().argmax(1) == part[0].float().argmax(1))
-        for k, (f, p) in enumerate(zip(full, part)):
-            d = (f[lo:lo + 32].float() - p.float()).abs().flatten(1).max(1)[0]
-            if k == 1:
-                d = d[same]
-            assert d.numel() == 0 or float(d.max()) <= 0.15, (lo, k, float(d.max()))
-    # bf16 storage through 152 layers against the fp32 oracle: no 1e-3 claim here (that is config 2, fp32 storage).  Rounding
-    # every activation and folded weight to 8 significant bits perturbs each layer by ~0.4 %, and a RANDOMLY INITIALISED
-    # 152-layer net amplifies perturbations (it is not the contraction a trained net is): measured 0.20 relative L2 on the
-    # pooled features and 0.06 absolute on the logits (|W_classifier| is small at init); asserted at 0.35 / 0.15.  The
-    # arithmetic of every kernel on this path is pinned at 1.2e-2 by tests/test_production_shapes_gpu.py.
-    # pred_nouns is not compared: it is conditioned on argmax(pred_verb), and this randomly initialised head's 504 verb logits
-    # span 0.26 -- bf16 legitimately flips near-ties, which swaps the whole role table (the gt-verb branch has no such switch).
+    _slices_equal_full(net, img, verb, full, (0, 3072, B - 1024), 1024)
     with torch.no_grad():
         fv = net.convnet_verbs(img[3040:3048].contiguous()).float().cpu()
         wv = ora.convnet_verbs(img[3040:3048].float().cpu())
     rel = float((fv - wv).norm() / wv.norm())
-    print("config3 bf16 vs fp32 oracle, pooled verb features: relative L2 error %.4f" % rel)
-    assert rel <= 0.35, rel
+    print("REPORTED config3 bf16 vs fp32 oracle (8 images, end to end through 152 layers), pooled verb features: relative L2 error %.4f" % rel)
+    assert rel < 1.0                                   # sanity only (an unrelated tensor gives ~1.4); see the docstring
     for f, w, name in ((full[0], want[0], "verb"), (full[2], want[2], "gt_nouns")):
         err = float((f[3040:3048].float().cpu() - w).abs().max())
-        print("config3 bf16 vs fp32 oracle, %s logits: max abs err %.4f (logit range %.3f)" % (name, err, float(w.abs().max())))
-        assert err <= 0.15, (name, err)
-    del full, parts
+        print("REPORTED config3 bf16 vs fp32 oracle, %s logits: max abs err %.4f (logit range %.3f)" % (name, err, float(w.abs().max())))
+    del full
     # train mode: one step's invariants at the full batch
     net.train()
     nouns = torch.randint(0, 2001, (B, 3, 6), generator=g).cuda()
@@ -134,6 +133,70 @@ def test_config3_resnet152_bf16_batch6144_slicing_oracle_and_train_invariants():
     assert not torch.equal(rv0, net.convnet_verbs.model.layer3[5].bn2.running_var)
     assert int(net.state_dict()["convnet_nouns.model.bn1.num_batches_tracked"]) == 2        # two passes' worth (model.py:176-178)
     assert int(net.state_dict()["convnet_verbs.model.bn1.num_batches_tracked"]) == 1
+
+
+def test_config5_resnet152_fp8_T8_batch8192_at_its_workload():
+    """BASELINE config 5 at its per-GPU workload: ResNet-152 with the e4m3 3x3 convolutions (`fp8=True`), T = 8, batch 8192.
+    The reference has no fp8 code (parity unpinned: what the fp8 kernels must compute is defined and tested at kernel level in
+    tests/test_fp8_gpu.py); here the FULL-SIZE run is held to size-independent properties: the expected number of fp8 launches
+    (every eligible 3x3 of both backbones: 8 + 36 + 3 = 47 per pass), finite logits, 1024-image slices bit-identical to the full
+    batch in eval mode, and one training step (reference sr.py:63-83) with finite loss, a gradient on every trainable parameter
+    and the BatchNorm buffers of both backbones updated (model.py:176-178: the noun backbone twice)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from situation_recognition_amd import ops
+    from situation_recognition_amd.imsitu_encoder import imsitu_encoder
+    from situation_recognition_amd.model import FCGGNN
+    torch.manual_seed(21)
+    B, T = 8192, 8
+    net = FCGGNN(imsitu_encoder.synthetic(), 2048, steps=T, backbone=152, dtype=torch.bfloat16, fp8=True).cuda()
+    eligible = sum(1 for convs, _ in net.convnet_verbs._plan()[1] if convs[1].fp8_eligible())
+    assert eligible == 8 + 36 + 3
+    img = _device_images(B, 8)
+    g = torch.Generator().manual_seed(8)
+    verb = torch.randint(0, 504, (B,), generator=g).cuda()
+    nouns = torch.randint(0, 2001, (B, 3, 6), generator=g).cuda()
+    calls = []
+    fp8_conv = ops.conv3x3_fp8
+
+    def counted(xq, wq, dq, Cout, stride=1, want_stats=False):
+        calls.append((tuple(xq.shape), Cout, stride))
+        return fp8_conv(xq, wq, dq, Cout, stride=stride, want_stats=want_stats)
+
+    ops.conv3x3_fp8 = counted
+    try:
+        net.eval()
+        with torch.no_grad():
+            full = net(img, verb)
+        assert len(calls) == 2 * eligible, len(calls)                   # one pass per backbone, every eligible 3x3 in e4m3
+        assert all(c[0][0] == B for c in calls)
+        for f in full:
+            assert torch.isfinite(f).all()
+        _slices_equal_full(net, img, verb, full, (0, B - 1024), 1024)
+        del full
+        calls.clear()
+        net.train()
+        rv0 = net.convnet_nouns.model.layer3[20].bn2.running_var.clone()
+        pv, pn, pg = net(img, verb)
+        assert len(calls) == 2 * eligible
+    finally:
+        ops.conv3x3_fp8 = fp8_conv
+    for t in (pv, pn, pg):
+        assert torch.isfinite(t).all()
+    assert tuple(pv.shape) == (B, 504) and tuple(pn.shape) == (B, 6, 2001) and tuple(pg.shape) == (B, 6, 2001)
+    loss = net.verb_loss(pv, verb) + net.nouns_loss(pn, nouns)
+    assert torch.isfinite(loss) and 5.0 < float(net.verb_loss(pv, verb)) < 9.0          # ~ ln(504) at init
+    loss.backward()
+    params = [p for p in net.parameters() if p.requires_grad]
+    for k, p in net.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, k
+    gn = torch.nn.utils.clip_grad_norm_(params, 1.0)
+    assert torch.isfinite(gn)
+    torch.optim.Adamax(params, lr=0.002).step()
+    assert not torch.equal(rv0, net.convnet_nouns.model.layer3[20].bn2.running_var)
+    sd = net.state_dict()
+    assert int(sd["convnet_nouns.model.bn1.num_batches_tracked"]) == 2 and int(sd["convnet_verbs.model.bn1.num_batches_tracked"]) == 1
 
 
 def test_gram_statistics_route_matches_statistics_only_launch_in_the_backbone():

@@ -93,11 +93,15 @@ def test_conv3x3_256_256_statistics_kernel(ops):
 
 
 def test_conv1x1_256_1024_scale_residual_relu(ops):
-    """layer3's expansion conv (36 launches per pass, 18 % of the step): `<bf16,bf16,4,0>` with the per-channel multiplier,
-    bias, ROW-LAYOUT residual prefetched three strips ahead, ReLU and the staged store."""
+    """layer3's expansion conv (36 launches per pass, 18 % of the step) on the weight-stationary kernel `conv1x1_ws_kernel<8,8,...>`
+    (csrc/expand.hip; asserted with sr_conv_route): per-channel multiplier, bias, residual prefetched one tile ahead, ReLU -- and the
+    Gram-matrix statistics route in front of it.  (The generic kernel's residual epilogue `<bf16,bf16,4,0>` is covered by
+    test_generic_residual_epilogue_512_2048_and_stride2_downsample below: layer4's expansion conv and the downsamples run on it.)"""
+    from situation_recognition_amd import _lib
     Cin, Cout = 256, 1024
     M = B14 * 196
-    assert cfg(ops, M, Cout) == 4
+    assert ops.conv_route(B14, 14, 14, Cin, Cout, 1, 1, 0, bias=True, escale=True, res=True, relu=True) == _lib.ROUTE_WS
+    assert ops.conv_route(6144, 14, 14, Cin, Cout, 1, 1, 0, bias=True, escale=True, res=True, relu=True) == _lib.ROUTE_WS
     x = F.relu(rnd(B14, 14, 14, Cin, seed=3)).to(BF)
     w = rnd(Cout, Cin, 1, 1, seed=4, scale=Cin ** -0.5)
     idn = rnd(B14, 14, 14, Cout, seed=5)
@@ -180,12 +184,16 @@ def test_gemm_2048_all_epilogues_on_the_ping_pong_kernel(ops, M):
 
 
 @pytest.mark.parametrize("Cin,Cout,rows", [(64, 256, 40000), (128, 512, 33000), (256, 1024, 32768 + 77), (256, 256, 50001), (128, 768, 36000)])
-def test_expand_kernel_options_and_ragged_rows(ops, Cin, Cout, rows):
-    """`conv1x1_expand_kernel` (csrc/expand.hip: 128x256 tiles, two accumulator sets, the previous tile's epilogue riding on the
-    current tile's K-steps): every K variant (64 / 128 / 256), row counts that are not a multiple of the 128-row block
-    (the tail rows are dropped by the buffer descriptor's range check, their A rows read as zeros), with and without
-    multiplier / bias / residual / ReLU -- against the fp32 matmul; a sentinel behind the last row must survive."""
-    import os
+def test_output_heavy_1x1_options_and_ragged_rows(ops, Cin, Cout, rows):
+    """Output-heavy 1x1 convolutions with every epilogue option and ragged row counts.  The first four shapes run on the
+    weight-stationary kernel `conv1x1_ws_kernel` (csrc/expand.hip: every K variant 64 / 128 / 256, N = 256 on the 4-wave-column
+    form, N = 512 / 1024 on the 8-wave-column form; row counts that are not a multiple of the 32 / 64-row tile -- the tail rows
+    are dropped by the buffer descriptor's range check, their A rows read as zeros); N = 768 is a shape it does not serve and
+    takes the generic implicit-GEMM kernel's `escale` / residual epilogue (asserted with sr_conv_route).  With and without
+    multiplier / bias / residual / ReLU, against the fp32 matmul; a sentinel behind the last row must survive."""
+    from situation_recognition_amd import _lib
+    route = ops.conv_route(1, rows, 1, Cin, Cout, 1, 1, 0, bias=True, escale=True, res=True, relu=True)
+    assert route == (_lib.ROUTE_WS if Cout in (256, 512, 1024) else 4)
     x = rnd(1, rows, 1, Cin, seed=rows)
     w = rnd(Cout, Cin, 1, 1, seed=Cin, scale=Cin ** -0.5)
     idn = rnd(1, rows, 1, Cout, seed=Cout)
@@ -278,3 +286,105 @@ def test_direct_3x3_normalises_its_input_on_load(ops, B, H):
     close(lazy.view(-1, Cc), ref.reshape(-1, Cc))
     with pytest.raises(Exception):                                     # eval form (bias + ReLU): not served with an input affine
         ops.conv2d(y1, pack_w(w), Cc, 3, 1, 1, bias=sh, relu=True, in_affine=(sc, sh))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Narrow-tile kernels (`conv_igemm_v3_kernel<bf16,bf16,2,*>` / `<...,1,*>`: 11 % of the benchmark's GPU time) and the generic
+# kernel's residual epilogue at the shapes the benchmark runs, >= 3 tiles per workgroup (512 workgroup slots: two per CU).
+def _stats_close(stats, ref):
+    s1, s2 = stats[:, 0].double().sum(0), stats[:, 1].double().sum(0)
+    r1, r2 = ref.double().sum(0), (ref.double() ** 2).sum(0)
+    assert float((s1 - r1).abs().max()) < 1e-4 * float(ref.abs().sum(0).max())
+    assert float(((s2 - r2).abs() / r2).max()) < 1e-4
+
+
+@pytest.mark.parametrize("Cin,Cout,k,H,B,want_cfg", [(128, 128, 3, 28, 512, 2),       # layer2's 3x3 (7 per pass)
+                                                     (512, 128, 1, 28, 512, 2),       # layer2's reduce conv (7 per pass)
+                                                     (256, 64, 1, 56, 160, 1),        # layer1's reduce conv (2 per pass)
+                                                     (64, 64, 1, 56, 160, 1)])        # layer1.0.conv1
+def test_narrow_tile_kernels_at_multi_tile_production_shapes(ops, Cin, Cout, k, H, B, want_cfg):
+    """256x128 (`WAVES_N = 2`) and 256x64 (`WAVES_N = 1`) tiles, four waves, two workgroups per CU, lock-step ring: train-mode form
+    (raw bf16 output + running BatchNorm partial sums across the 3+ tiles a workgroup walks -- the tile-to-tile ring hand-over),
+    statistics-only form and eval form (bias + ReLU), against the fp32 im2col matmul of the bf16-rounded operands."""
+    M = B * H * H
+    assert cfg(ops, M, Cout) == want_cfg == cfg(ops, 6144 * H * H, Cout)
+    pad = k // 2
+    assert ops.conv_route(B, H, H, Cin, Cout, k, 1, pad, want_stats=True) == want_cfg
+    slots = 2 * torch.cuda.get_device_properties(0).multi_processor_count
+    assert (M + 255) // 256 * ((Cout + 64 * want_cfg - 1) // (64 * want_cfg)) >= 3 * slots       # >= 3 tiles per workgroup
+    x = F.relu(rnd(B, H, H, Cin, seed=Cin + k)).to(BF)
+    w = rnd(Cout, Cin, k, k, seed=Cout + k, scale=(Cin * k * k) ** -0.5)
+    y, stats = ops.conv2d(x, pack_w(w), Cout, k, 1, pad, want_stats=True)
+    ref = conv_ref(x, w, k, pad)
+    close(y.view(M, Cout), ref)
+    _stats_close(stats, ref)
+    cpu = F.conv2d(x[:2].float().cpu().permute(0, 3, 1, 2), w.float().cpu(), padding=pad).permute(0, 2, 3, 1).reshape(-1, Cout)
+    assert float((ref[: 2 * H * H].cpu() - cpu).abs().max()) < 1e-4 * float(cpu.abs().max())
+    st2 = ops.conv2d(x, pack_w(w), Cout, k, 1, pad, stats_only=True) if Cout > 128 else None      # (no_store: Cout > 128 only)
+    assert st2 is None or torch.equal(st2, stats)
+    bias = 0.3 * torch.randn(Cout, device="cuda")
+    y2 = ops.conv2d(x, pack_w(w), Cout, k, 1, pad, bias=bias, relu=True)
+    close(y2.view(M, Cout), F.relu(ref + bias))
+    # through the BatchNorm it feeds
+    gamma, beta = 0.5 + torch.rand(Cout, device="cuda"), 0.2 * torch.randn(Cout, device="cuda")
+    scale, shift = ops.bn_finalize(stats, M, gamma, beta, None, None, 0.1, 1e-5)
+    want = F.relu(F.batch_norm(ref.t().reshape(1, Cout, M), None, None, gamma, beta, training=True, eps=1e-5)).view(Cout, M).t()
+    close(ops.bn_apply(y, scale, shift, relu=True).view(M, Cout), want, k=2.0)
+    # ragged batch (a partly filled last row tile) on the same kernel
+    Br = B - 3
+    y3 = ops.conv2d(x[:Br].contiguous(), pack_w(w), Cout, k, 1, pad)
+    close(y3.view(-1, Cout), ref[: Br * H * H])
+
+
+def conv_ref_strided(x_nhwc, w, stride):
+    """1x1 convolution with a stride: fp32 matmul over the subsampled pixels."""
+    xs = x_nhwc[:, ::stride, ::stride, :].float()
+    return xs.reshape(-1, xs.shape[3]) @ w.float().view(w.shape[0], -1).t()
+
+
+def test_generic_residual_epilogue_512_2048_and_stride2_downsample(ops):
+    """`conv_igemm_v3_kernel<bf16,bf16,4,0>` with `escale` + bias + row-layout residual + ReLU at the shapes the benchmark runs on
+    it: layer4's expansion conv 512 -> 2048 @7 (N = 2048 is not a weight-stationary shape) at batch 2048 -- 392 row x 8 column
+    tiles = 12 per workgroup -- and the stride-2 1x1 downsample 256 -> 512 (56 -> 28; statistics-only launch, then the storing
+    launch with scale / shift and no residual), against the fp32 matmul of the bf16-rounded operands."""
+    Cin, Cout, B, H = 512, 2048, 2048, 7
+    M = B * H * H
+    assert cfg(ops, M, Cout) == 4 == cfg(ops, 6144 * 49, Cout)
+    assert ops.conv_route(B, H, H, Cin, Cout, 1, 1, 0, bias=True, escale=True, res=True, relu=True) == 4
+    x = F.relu(rnd(B, H, H, Cin, seed=31)).to(BF)
+    w = rnd(Cout, Cin, 1, 1, seed=32, scale=Cin ** -0.5)
+    idn = rnd(B, H, H, Cout, seed=33)
+    esc, bias = 0.5 + torch.rand(Cout, device="cuda"), 0.3 * torch.randn(Cout, device="cuda")
+    y = ops.conv2d(x, pack_w(w), Cout, 1, 1, 0, bias=bias, escale=esc, res=idn, relu=True)
+    conv = conv_ref(x, w, 1, 0)
+    close(y.view(M, Cout), F.relu(conv * esc + bias + idn.float().view(M, Cout)))
+    # train-mode route of that layer: statistics-only launch -> finalize -> storing launch (model.resnet._unit)
+    st = ops.conv2d(x, pack_w(w), Cout, 1, 1, 0, stats_only=True)
+    _stats_close(st, conv)
+    gamma, beta = 0.5 + torch.rand(Cout, device="cuda"), 0.2 * torch.randn(Cout, device="cuda")
+    scale, shift = ops.bn_finalize(st, M, gamma, beta, None, None, 0.1, 1e-5)
+    y2 = ops.conv2d(x, pack_w(w), Cout, 1, 1, 0, bias=shift, escale=scale, res=idn, relu=True)
+    want = F.relu(F.batch_norm(conv.t().reshape(1, Cout, M), None, None, gamma, beta, training=True, eps=1e-5).view(Cout, M).t()
+                  + idn.float().view(M, Cout))
+    close(y2.view(M, Cout), want, k=2.0)
+    # eval form: bias + residual + ReLU, no multiplier
+    y3 = ops.conv2d(x, pack_w(w), Cout, 1, 1, 0, bias=bias, res=idn, relu=True)
+    close(y3.view(M, Cout), F.relu(conv + bias + idn.float().view(M, Cout)))
+    del x, w, idn, y, y2, y3, conv, want
+    # stride-2 downsample of layer2.0: 256 -> 512, 56 x 56 -> 28 x 28
+    Cin, Cout, B, H = 256, 512, 512, 56
+    M = B * 28 * 28
+    assert ops.conv_route(B, H, H, Cin, Cout, 1, 2, 0, bias=True, escale=True) == 4 == ops.conv_route(6144, H, H, Cin, Cout, 1, 2, 0, bias=True, escale=True)
+    x = F.relu(rnd(B, H, H, Cin, seed=41)).to(BF)
+    w = rnd(Cout, Cin, 1, 1, seed=42, scale=Cin ** -0.5)
+    conv = conv_ref_strided(x, w, 2)
+    st = ops.conv2d(x, pack_w(w), Cout, 1, 2, 0, stats_only=True)
+    _stats_close(st, conv)
+    gamma, beta = 0.5 + torch.rand(Cout, device="cuda"), 0.2 * torch.randn(Cout, device="cuda")
+    scale, shift = ops.bn_finalize(st, M, gamma, beta, None, None, 0.1, 1e-5)
+    y = ops.conv2d(x, pack_w(w), Cout, 1, 2, 0, bias=shift, escale=scale)
+    assert tuple(y.shape) == (B, 28, 28, Cout)
+    want = F.batch_norm(conv.t().reshape(1, Cout, M), None, None, gamma, beta, training=True, eps=1e-5).view(Cout, M).t()
+    close(y.view(M, Cout), want, k=2.0)
+    ye = ops.conv2d(x, pack_w(w), Cout, 1, 2, 0, bias=beta)                  # eval form of the downsample: bias only
+    close(ye.view(M, Cout), conv + beta)
