@@ -47,6 +47,12 @@ extern "C" {
 #define SR_ABI_VERSION 3
 int sr_abi_version(void);
 
+/* Launches that follow (from any thread) size their persistent grids for 1/share of the device's compute units (share 1..8;
+ * default 1, or the SR_CU_SHARE environment variable): `share` streams that run the same kind of work side by side -- the two
+ * backbones of FCGGNN.forward, reference model.py:159,116 -- then co-reside on disjoint CUs instead of each launching a
+ * full-chip grid that queues behind the other's.  Returns the previous share, or SR_ERR_ARG. */
+int sr_set_cu_share(int share);
+
 /* One (activation, weight) operand pair of a GEMM: contributes A[M,K] . W[N,K]^T. */
 typedef struct sr_kpair {
   const void* A; /* [M, K] row-major, row stride lda (elements)          */

@@ -47,6 +47,7 @@ class ConvArgs(C.Structure):
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 SIGNATURES = {
     "sr_abi_version": [],
+    "sr_set_cu_share": [_I],
     "sr_gemm": [C.POINTER(GemmArgs), _I, _P],
     "sr_gemm_stats_tiles": [_I, _I],
     "sr_gemm_tile_cfg": [_I, _I, _I, _I],

@@ -58,16 +58,20 @@ inline bool sr_set_dynamic_lds_tagged(const void* kernel, int bytes) {
   __atomic_store_n(&done[d], 1u, __ATOMIC_RELEASE);
   return true;
 }
+// sr_set_cu_share (elementwise.hip): the persistent kernels size their grids for 1/share of the chip, so that the launches of
+// `share` concurrent streams co-reside on disjoint sets of CUs instead of queueing behind each other's full-chip grids.
+extern int sr_cu_share_value;
 inline int sr_num_cus() {
   static int cache[SR_MAX_DEV] = {};
   const int d = sr_cur_dev();
-  if (d < 0) return 256;
+  const int share = __atomic_load_n(&sr_cu_share_value, __ATOMIC_RELAXED);
+  if (d < 0) return 256 / share;
   int n = __atomic_load_n(&cache[d], __ATOMIC_ACQUIRE);
   if (n <= 0) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
     __atomic_store_n(&cache[d], n, __ATOMIC_RELEASE);
   }
-  return n;
+  return n / share;
 }
 
 

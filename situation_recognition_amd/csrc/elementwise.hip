@@ -2,6 +2,8 @@
 // stem layout prep, train-mode BatchNorm finalize/apply, pooling, transpose (+ column
 // sums), cast, dropout.  All of them stream 16 bytes per lane (cdna_hip_programming.md
 // Guideline 13) with grid-stride loops capped at 256 CUs x 8 workgroups.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -392,6 +394,12 @@ __global__ void dropout_half_kernel(const T* __restrict__ x, T* __restrict__ y, 
   else return SR_ERR_DTYPE;
 
 extern "C" int sr_abi_version(void) { return SR_ABI_VERSION; }
+
+int sr_cu_share_value = [] { const char* e = getenv("SR_CU_SHARE"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+extern "C" int sr_set_cu_share(int share) {
+  if (share < 1 || share > 8) return SR_ERR_ARG;
+  return __atomic_exchange_n(&sr_cu_share_value, share, __ATOMIC_RELAXED);
+}
 
 extern "C" int sr_stem_prep(const float* img, void* out, int B, int H, int W, int dtype, void* stream) {
   if (!img || !out || B <= 0 || H <= 0 || W <= 0) return SR_ERR_ARG;

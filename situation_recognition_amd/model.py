@@ -829,6 +829,7 @@ class FCGGNN(nn.Module):
         self.overlap_backbones = None if env is None else env not in ("0", "")
         self._side_streams = {}
         self._noun_feat_cache = None
+        self.backbone_cu_share = int(os.environ.get("SR_BACKBONE_CU_SHARE", "2"))   # see forward(): 2 = each overlapped pass on half the CUs
         # one train-mode pass for both backbones while their (frozen) weights are identical -- see forward()
         self.share_identical_backbones = os.environ.get("SR_SHARE_BACKBONES", "1") not in ("0", "")
 
@@ -899,12 +900,21 @@ class FCGGNN(nn.Module):
             share = self.convnet_verbs.dtype == self.convnet_nouns.dtype and not (self.convnet_verbs.use_graphs or self.convnet_nouns.use_graphs)
             prepped = self.convnet_verbs.prepare_input(img) if share else None
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                feat = self.convnet_nouns(img, bn_updates=2, prepped=prepped)
-            img.record_stream(side)
-            if prepped is not None:
-                prepped[0].record_stream(side)
-            pred_verb = self._verb_from_features(self.convnet_verbs(img, prepped=prepped), batch_size)
+            # Each pass sizes its persistent grids for HALF of the compute units (`sr_set_cu_share`): the two streams' launches then
+            # co-reside on disjoint CUs for their whole duration, instead of two full-chip grids of which the second only moves in as
+            # the first one's last round of tiles drains -- 2 x 588 row tiles of a 768-image layer3 launch are 4.6 of 5 rounds on
+            # 128 CUs each, not 2 x (2.3 of 3) rounds on 256.
+            prev = ops.set_cu_share(self.backbone_cu_share)
+            try:
+                with torch.cuda.stream(side):
+                    feat = self.convnet_nouns(img, bn_updates=2, prepped=prepped)
+                img.record_stream(side)
+                if prepped is not None:
+                    prepped[0].record_stream(side)
+                feat_v = self.convnet_verbs(img, prepped=prepped)
+            finally:
+                ops.set_cu_share(prev)
+            pred_verb = self._verb_from_features(feat_v, batch_size)
             main.wait_stream(side)
             feat.record_stream(main)
         else:

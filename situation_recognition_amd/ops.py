@@ -81,6 +81,13 @@ def gemm(pairs, N=None, bias=None, bias_scale=1.0, bias2=None, act=ACT_NONE, res
     return (out, out2) if two else out
 
 
+def set_cu_share(share):
+    """Persistent grids of the launches that follow are sized for 1/share of the chip (sr_set_cu_share); returns the previous value."""
+    rc = lib().sr_set_cu_share(int(share))
+    check(min(rc, 0), "sr_set_cu_share")
+    return rc
+
+
 def stats_tiles(M, N):
     return lib().sr_gemm_stats_tiles(int(M), int(N))
 
