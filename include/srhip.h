@@ -224,9 +224,18 @@ int sr_avgpool(const void* x, void* y, int B, int HW, int C, int dtype, void* st
 
 /* node[b*R+r,:] = relu(feat[b,:] * role_emb[role_ids[verb[b]][r],:] * verb_emb[verb[b],:])
  * (reference model.py:117-144 incl. the encoder lookup imsitu_encoder.py:172-180 done on device).
- * role_table: int32 [V][R]; feat_relu != 0 applies relu to feat first (unused by the noun path). */
+ * role_table: int32 [V][R].
+ *
+ * PACKED ROLE ROWS (`offs` != NULL in this and the two functions below).  A verb with k < R roles has R - k padded role slots.  Their
+ * nodes start at exactly 0 (role_emb's padding row is 0, model.py:95-97), their adjacency row is only their own diagonal 1
+ * (imsitu_encoder.py:209-229) and no real role reads them, so through all T steps EVERY padded slot of EVERY image holds the same
+ * vector -- one trajectory that depends on the weights alone -- and the reference computes it B*(R-k) times.  In the packed form
+ * only the real roles' rows exist: offs int32 [B+1] = prefix sums of the images' role counts, image b's role r is row offs[b] + r,
+ * and ONE more row, offs[B], stands for all padded slots (the caller zero-fills it in the node tensor; sr_ggnn_aggregate copies it
+ * through as "image" B).  The caller expands the packed classifier output back to [B, R, L] (padded slots <- the shared row) and
+ * folds the gradients of all padded slots into the shared row, so results and gradients equal the full form's. */
 int sr_node_init_fwd(const void* feat, const float* role_emb, const float* verb_emb, const int64_t* verbs,
-                     const int32_t* role_table, void* node, int B, int R, int D, int dtype, void* stream);
+                     const int32_t* role_table, void* node, int B, int R, int D, int dtype, const int32_t* offs, void* stream);
 /* gradients of the above: fp32 d_role_emb [NR+1,D] and d_verb_emb [V,D], both written IN FULL (the padding row NR and
  * the rows of verbs / roles absent from the batch get zeros, as nn.Embedding(padding_idx) does) with a fixed summation
  * order -- no atomics, bit-reproducible.  The caller supplies the batch grouped by verb and the role table's inverted index:
@@ -238,13 +247,14 @@ int sr_node_init_fwd(const void* feat, const float* role_emb, const float* verb_
 int sr_node_init_bwd(const void* dnode, const void* feat, const float* role_emb, const float* verb_emb,
                      const int32_t* order, const int32_t* seg, const int32_t* role_table, const int32_t* inv_ptr,
                      const int32_t* inv_slot, float* scratch, float* d_role_emb, float* d_verb_emb,
-                     int B, int R, int D, int V, int NR, int dtype, void* stream);
+                     int B, int R, int D, int V, int NR, int dtype, const int32_t* offs /* packed rows of dnode, or NULL */, void* stream);
 
 /* out[b,i,:] = sum_j A[verb[b]][i][j] * h[b,j,:] (+ add[b,i,:])   (transpose != 0: A^T)
  * The role-graph message step of GGSNN.forward (model.py:66-77) in its algebraic form, with the
- * adjacency lookup of imsitu_encoder.py:209-229 done on device from adj_table fp32 [V][R][R]. */
+ * adjacency lookup of imsitu_encoder.py:209-229 done on device from adj_table fp32 [V][R][R].
+ * offs != NULL: packed role rows (see sr_node_init_fwd): h / add / out hold offs[B] + 1 rows. */
 int sr_ggnn_aggregate(const void* h, const float* adj_table, const int64_t* verbs, const void* add, void* out,
-                      int B, int R, int D, int transpose, int dtype, void* stream);
+                      int B, int R, int D, int transpose, int dtype, const int32_t* offs, void* stream);
 
 /* GRU backward, stage 1 (model.py:84,82-83,80 differentiated):
  *   dc_pre = dh*z*(1-c^2); dz_pre = dh*(c-h)*z*(1-z); dh_acc = dh*(1-z) */

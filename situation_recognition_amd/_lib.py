@@ -71,9 +71,9 @@ SIGNATURES = {
     "sr_bn_apply": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "sr_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P],
     "sr_avgpool": [_P, _P, _I, _I, _I, _I, _P],
-    "sr_node_init_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "sr_node_init_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "sr_ggnn_aggregate": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sr_node_init_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "sr_node_init_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "sr_ggnn_aggregate": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "sr_gru_bwd1": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "sr_gru_bwd2": [_P, _P, _P, _P, _P, _L, _I, _P],
     "sr_transpose": [_P, _L, _P, _L, _L, _L, _I, _I, _P, _F, _P],

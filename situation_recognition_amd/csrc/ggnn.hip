@@ -17,10 +17,13 @@ inline unsigned grid_for(long work_items) {
 }
 
 // node[b,r,:] = relu(feat[b,:] * role_emb[role_table[verb_b][r],:] * verb_emb[verb_b,:])
+// Packed form (`offs` != NULL, [B+1] prefix sums of the images' role counts): only the rows of REAL roles exist -- image b's role r
+// is row offs[b] + r, r < offs[b+1] - offs[b] -- see sr_node_init_fwd in include/srhip.h.
 template <typename T>
 __global__ void node_init_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ role_emb,
                                      const float* __restrict__ verb_emb, const int64_t* __restrict__ verbs,
-                                     const int32_t* __restrict__ role_table, T* __restrict__ node, int B, int R, int D) {
+                                     const int32_t* __restrict__ role_table, T* __restrict__ node, int B, int R, int D,
+                                     const int32_t* __restrict__ offs) {
   constexpr int N = Vec16<T>::N;
   const int dv = D / N;
   const long total = (long)B * dv;
@@ -32,12 +35,14 @@ __global__ void node_init_fwd_kernel(const T* __restrict__ feat, const float* __
     float fx[N], ve[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) { fx[k] = f.get(k); ve[k] = verb_emb[v * D + d + k]; }
-    for (int r = 0; r < R; ++r) {
+    const long row0 = offs ? offs[b] : b * R;
+    const int nr = offs ? offs[b + 1] - offs[b] : R;
+    for (int r = 0; r < nr; ++r) {
       const long rid = role_table[v * R + r];
       Vec16<T> o;
 #pragma unroll
       for (int k = 0; k < N; ++k) o.set(k, fmaxf((fx[k] * role_emb[rid * D + d + k]) * ve[k], 0.f));  // model.py:143 order
-      st16<T>(node + (b * R + r) * D + d, o);
+      st16<T>(node + (row0 + r) * D + d, o);
     }
   }
 }
@@ -54,7 +59,8 @@ __global__ __launch_bounds__(64) void node_init_bwd1_kernel(const T* __restrict_
                                                             const float* __restrict__ role_emb, const float* __restrict__ verb_emb,
                                                             const int32_t* __restrict__ order, const int32_t* __restrict__ seg,
                                                             const int32_t* __restrict__ role_table, float* __restrict__ S,
-                                                            float* __restrict__ d_verb, int R, int D, int NR) {
+                                                            float* __restrict__ d_verb, int R, int D, int NR,
+                                                            const int32_t* __restrict__ offs) {
   constexpr int N = Vec16<T>::N;
   const int v = blockIdx.x;
   const int d = (blockIdx.y * 64 + threadIdx.x) * N;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(64) void node_init_bwd1_kernel(const T* __restrict_
 #pragma unroll
     for (int r = 0; r < kMaxR; ++r) {
       if (r < R && rid[r] != NR) {
-        Vec16<T> g = ld16<T>(dnode + (b * R + r) * D + d);
+        Vec16<T> g = ld16<T>(dnode + ((offs ? (long)offs[b] : b * R) + r) * D + d);     // (packed: a real role r is always < the image's count)
 #pragma unroll
         for (int k = 0; k < N; ++k) {
           const float fx = f.get(k);
@@ -122,27 +128,36 @@ __global__ __launch_bounds__(64) void node_init_bwd2_kernel(const float* __restr
 
 // out[b,i,:] = sum_j A[i][j] h[b,j,:] (+ add).  One workgroup = one image: the R x R adjacency of
 // the image's verb is staged in LDS once, every lane keeps its R-row column strip in registers.
+// Packed form (`offs` != NULL): image b owns the rows offs[b] .. offs[b+1]-1 (its real roles; the leading block of its verb's
+// adjacency), and "image" B is the single shared row of the padded roles (adjacency = its own diagonal 1: out = h (+ add)).
 template <typename T, int RR>
 __global__ __launch_bounds__(kThreads) void aggregate_kernel(const T* __restrict__ h, const float* __restrict__ adj,
                                                              const int64_t* __restrict__ verbs, const T* __restrict__ add,
-                                                             T* __restrict__ out, int B, int D, int transpose) {
+                                                             T* __restrict__ out, int B, int D, int transpose,
+                                                             const int32_t* __restrict__ offs) {
   constexpr int N = Vec16<T>::N;
   __shared__ float A[RR * RR];
   const int dv = D / N;
-  for (long b = blockIdx.x; b < B; b += gridDim.x) {
+  const long nimg = offs ? (long)B + 1 : B;
+  for (long b = blockIdx.x; b < nimg; b += gridDim.x) {
     __syncthreads();
+    const bool padrow = b == B;
     if (threadIdx.x < RR * RR) {
       const int i = threadIdx.x / RR, j = threadIdx.x % RR;
-      A[threadIdx.x] = adj[verbs[b] * (RR * RR) + (transpose ? j * RR + i : i * RR + j)];
+      A[threadIdx.x] = padrow ? (i == j ? 1.f : 0.f) : adj[verbs[b] * (RR * RR) + (transpose ? j * RR + i : i * RR + j)];
     }
     __syncthreads();
+    const long row0 = offs ? (long)offs[padrow ? B : b] : b * RR;
+    const int nr = offs ? (padrow ? 1 : offs[b + 1] - offs[b]) : RR;
     for (int c = threadIdx.x; c < dv; c += kThreads) {
-      const long base = b * RR * (long)D + c * N;
+      const long base = row0 * (long)D + c * N;
       Vec16<T> hv[RR];
 #pragma unroll
-      for (int j = 0; j < RR; ++j) hv[j] = ld16<T>(h + base + (long)j * D);
+      for (int j = 0; j < RR; ++j)
+        if (j < nr) hv[j] = ld16<T>(h + base + (long)j * D);
 #pragma unroll
       for (int i = 0; i < RR; ++i) {
+        if (i >= nr) break;
         float s[N];
         if (add) {
           Vec16<T> a = ld16<T>(add + base + (long)i * D);
@@ -154,9 +169,11 @@ __global__ __launch_bounds__(kThreads) void aggregate_kernel(const T* __restrict
         }
 #pragma unroll
         for (int j = 0; j < RR; ++j) {
-          const float a = A[i * RR + j];
+          if (j < nr) {
+            const float a = A[i * RR + j];
 #pragma unroll
-          for (int k = 0; k < N; ++k) s[k] += a * hv[j].get(k);
+            for (int k = 0; k < N; ++k) s[k] += a * hv[j].get(k);
+          }
         }
         Vec16<T> o;
 #pragma unroll
@@ -205,12 +222,12 @@ __global__ void gru_bwd2_kernel(const T* __restrict__ drh, const T* __restrict__
 
 template <typename T>
 int launch_aggregate(const void* h, const float* adj, const int64_t* verbs, const void* add, void* out, int B, int R, int D,
-                     int transpose, hipStream_t st) {
-  const unsigned g = (unsigned)(B < 256 * 16 ? B : 256 * 16);
+                     int transpose, const int32_t* offs, hipStream_t st) {
+  const unsigned g = (unsigned)(B + 1 < 256 * 16 ? B + 1 : 256 * 16);
 #define AGG(RR)                                                                                                   \
   case RR:                                                                                                        \
     hipLaunchKernelGGL((aggregate_kernel<T, RR>), dim3(g), dim3(kThreads), 0, st, (const T*)h, adj, verbs,        \
-                       (const T*)add, (T*)out, B, D, transpose);                                                  \
+                       (const T*)add, (T*)out, B, D, transpose, offs);                                            \
     break;
   switch (R) {
     AGG(1) AGG(2) AGG(3) AGG(4) AGG(5) AGG(6) AGG(7) AGG(8)
@@ -229,13 +246,14 @@ int launch_aggregate(const void* h, const float* adj, const int64_t* verbs, cons
   else return SR_ERR_DTYPE;
 
 extern "C" int sr_node_init_fwd(const void* feat, const float* role_emb, const float* verb_emb, const int64_t* verbs,
-                                const int32_t* role_table, void* node, int B, int R, int D, int dtype, void* stream) {
+                                const int32_t* role_table, void* node, int B, int R, int D, int dtype, const int32_t* offs,
+                                void* stream) {
   if (!feat || !role_emb || !verb_emb || !verbs || !role_table || !node || B <= 0 || R <= 0 || D <= 0) return SR_ERR_ARG;
   const int n = dtype == SR_F32 ? 4 : 8;
   if (D % n) return SR_ERR_ARG;
   const long total = (long)B * (D / n);
   DT_SWITCH(dtype, hipLaunchKernelGGL(node_init_fwd_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
-                                      (const T*)feat, role_emb, verb_emb, verbs, role_table, (T*)node, B, R, D));
+                                      (const T*)feat, role_emb, verb_emb, verbs, role_table, (T*)node, B, R, D, offs));
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
@@ -243,7 +261,7 @@ extern "C" int sr_node_init_fwd(const void* feat, const float* role_emb, const f
 extern "C" int sr_node_init_bwd(const void* dnode, const void* feat, const float* role_emb, const float* verb_emb,
                                 const int32_t* order, const int32_t* seg, const int32_t* role_table, const int32_t* inv_ptr,
                                 const int32_t* inv_slot, float* scratch, float* d_role_emb, float* d_verb_emb, int B, int R, int D,
-                                int V, int NR, int dtype, void* stream) {
+                                int V, int NR, int dtype, const int32_t* offs, void* stream) {
   if (!dnode || !feat || !role_emb || !verb_emb || !order || !seg || !role_table || !inv_ptr || !inv_slot || !scratch ||
       !d_role_emb || !d_verb_emb || B <= 0 || R <= 0 || R > kMaxR || D <= 0 || V <= 0 || NR < 0)
     return SR_ERR_ARG;
@@ -252,7 +270,7 @@ extern "C" int sr_node_init_bwd(const void* dnode, const void* feat, const float
   const unsigned gy1 = (unsigned)((D / n + 63) / 64), gy2 = (unsigned)((D / 4 + 63) / 64);
   DT_SWITCH(dtype, hipLaunchKernelGGL(node_init_bwd1_kernel<T>, dim3((unsigned)V, gy1), dim3(64), 0, (hipStream_t)stream,
                                       (const T*)dnode, (const T*)feat, role_emb, verb_emb, order, seg, role_table, scratch,
-                                      d_verb_emb, R, D, NR));
+                                      d_verb_emb, R, D, NR, offs));
   SR_CHECK_LAUNCH();
   hipLaunchKernelGGL(node_init_bwd2_kernel, dim3((unsigned)NR + 1, gy2), dim3(64), 0, (hipStream_t)stream, scratch, verb_emb,
                      inv_ptr, inv_slot, d_role_emb, R, D, NR);
@@ -261,12 +279,12 @@ extern "C" int sr_node_init_bwd(const void* dnode, const void* feat, const float
 }
 
 extern "C" int sr_ggnn_aggregate(const void* h, const float* adj_table, const int64_t* verbs, const void* add, void* out,
-                                 int B, int R, int D, int transpose, int dtype, void* stream) {
+                                 int B, int R, int D, int transpose, int dtype, const int32_t* offs, void* stream) {
   if (!h || !adj_table || !verbs || !out || B <= 0 || R <= 0 || R > kMaxR || D <= 0) return SR_ERR_ARG;
   const int n = dtype == SR_F32 ? 4 : 8;
   if (D % n) return SR_ERR_ARG;
-  if (dtype == SR_F32) return launch_aggregate<float>(h, adj_table, verbs, add, out, B, R, D, transpose, (hipStream_t)stream);
-  if (dtype == SR_BF16) return launch_aggregate<bf16_t>(h, adj_table, verbs, add, out, B, R, D, transpose, (hipStream_t)stream);
+  if (dtype == SR_F32) return launch_aggregate<float>(h, adj_table, verbs, add, out, B, R, D, transpose, offs, (hipStream_t)stream);
+  if (dtype == SR_BF16) return launch_aggregate<bf16_t>(h, adj_table, verbs, add, out, B, R, D, transpose, offs, (hipStream_t)stream);
   return SR_ERR_DTYPE;
 }
 

@@ -615,27 +615,27 @@ class _GGNNFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, h0, adj, idx, R, verb, steps, shadow, *params):
+    def forward(ctx, h0, adj, idx, R, verb, steps, shadow, offs, *params):
         (Wp, bp, Wz, bz, Uz, buz, Wr, br, Ur, bur, Wh, bh, Uh, buh) = params
         dt = h0.dtype
         g = lambda p: shadow.get(p, dt)
         saved = []
         h = h0.contiguous()
         for _ in range(steps):
-            agg = h if verb else ops.aggregate(h, adj, idx, R)
+            agg = h if verb else ops.aggregate(h, adj, idx, R, offs=offs)
             n = ops.gemm([(agg, g(Wp))], bias=bp, bias_scale=1.0 if verb else float(R))
             z = ops.gemm([(n, g(Wz)), (h, g(Uz))], bias=bz, bias2=buz, act=ops.ACT_SIGMOID)
             r, rh = ops.gemm([(n, g(Wr)), (h, g(Ur))], bias=br, bias2=bur, act=ops.ACT_SIGMOID_MUL, aux1=h)
             h_new, c = ops.gemm([(n, g(Wh)), (rh, g(Uh))], bias=bh, bias2=buh, act=ops.ACT_TANH_BLEND, aux1=h, aux2=z)
             saved += [h, agg, n, z, r, rh, c]
             h = h_new
-        ctx.meta = (R, verb, steps, shadow, adj, idx)
+        ctx.meta = (R, verb, steps, shadow, adj, idx, offs)
         ctx.save_for_backward(*saved, *params)
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        R, verb, steps, shadow, adj, idx = ctx.meta
+        R, verb, steps, shadow, adj, idx, offs = ctx.meta
         tensors = ctx.saved_tensors
         saved, params = tensors[: 7 * steps], tensors[7 * steps:]
         (Wp, bp, Wz, bz, Uz, buz, Wr, br, Ur, bur, Wh, bh, Uh, buh) = params
@@ -673,7 +673,7 @@ class _GGNNFunction(torch.autograd.Function):
                 dh = ops.gemm([(dn, gT(Wp))], res=dacc)
             else:
                 dagg = ops.gemm([(dn, gT(Wp))])
-                dh = ops.aggregate(dagg, adj, idx, R, transpose=True, add=dacc)
+                dh = ops.aggregate(dagg, adj, idx, R, transpose=True, add=dacc, offs=offs)
             if tn:
                 ops.colsum(dz, gb["z"]); ops.colsum(dr, gb["r"]); ops.colsum(dc, gb["h"])
                 ops.colsum(dn, gb["p"], scale=1.0 if verb else float(R))
@@ -699,11 +699,11 @@ class _GGNNFunction(torch.autograd.Function):
         if tn:
             grads = (gP, gb["p"], gW["Wz"], gb["z"], gW["Uz"], gb["z"].clone(), gW["Wr"], gb["r"], gW["Ur"], gb["r"].clone(),
                      gW["Wh"], gb["h"], gW["Uh"], gb["h"].clone())
-            return (dh, None, None, None, None, None, None) + grads
+            return (dh, None, None, None, None, None, None, None) + grads
         blk = lambda g_, i, j: g_[i * D:(i + 1) * D, j * D:(j + 1) * D].contiguous()
         grads = (gP, gb["p"], blk(gZR, 0, 1), gb["z"], blk(gZR, 0, 0), gb["z"].clone(), blk(gZR, 1, 1), gb["r"], blk(gZR, 1, 0),
                  gb["r"].clone(), blk(gC, 0, 0), gb["h"], blk(gC, 0, 1), gb["h"].clone())
-        return (dh, None, None, None, None, None, None) + grads
+        return (dh, None, None, None, None, None, None, None) + grads
 
 
 class GGSNN(nn.Module):
@@ -722,10 +722,11 @@ class GGSNN(nn.Module):
     def _params(self):
         return tuple(itertools.chain.from_iterable((getattr(self, n).weight, getattr(self, n).bias) for n in self._ORDER))
 
-    def run(self, hidden_state, adj_table, verbs, R, verb):
+    def run(self, hidden_state, adj_table, verbs, R, verb, offs=None):
+        """`offs` (int32 [B+1]): `hidden_state` holds PACKED role rows -- see FCGGNN._pack_plan / sr_node_init_fwd."""
         if not hidden_state.is_cuda:
             raise SrError("GGSNN runs on an MI355X only (got a CPU tensor; no CPU fallback)")
-        return _GGNNFunction.apply(hidden_state, adj_table, verbs, R, verb, self.steps, self._shadow, *self._params())
+        return _GGNNFunction.apply(hidden_state, adj_table, verbs, R, verb, self.steps, self._shadow, offs, *self._params())
 
     def forward(self, hidden_state, mask=None, verb=False):
         if verb:
@@ -741,9 +742,10 @@ class _NodeInitFunction(torch.autograd.Function):
     scatters into the two embedding gradients.  The image features get no gradient (frozen backbone)."""
 
     @staticmethod
-    def forward(ctx, feat, role_w, verb_w, verbs, role_table):
+    def forward(ctx, feat, role_w, verb_w, verbs, role_table, offs=None, rows=None):
         ctx.save_for_backward(feat, role_w, verb_w, verbs, role_table)
-        return ops.node_init_fwd(feat.contiguous(), role_w, verb_w, verbs, role_table)
+        ctx.offs = offs
+        return ops.node_init_fwd(feat.contiguous(), role_w, verb_w, verbs, role_table, offs=offs, rows=rows)
 
     @staticmethod
     def backward(ctx, dnode):
@@ -752,8 +754,32 @@ class _NodeInitFunction(torch.autograd.Function):
         dnode = dnode.contiguous()
         if dnode.dtype != feat.dtype:
             dnode = ops.cast(dnode, feat.dtype)
-        ops.node_init_bwd(dnode, feat.contiguous(), role_w, verb_w, verbs, role_table, d_role, d_verb)
-        return None, d_role, d_verb, None, None
+        ops.node_init_bwd(dnode, feat.contiguous(), role_w, verb_w, verbs, role_table, d_role, d_verb, offs=ctx.offs)
+        return None, d_role, d_verb, None, None, None, None
+
+
+class _ExpandRowsFunction(torch.autograd.Function):
+    """Packed classifier output [rows + 1, L] -> the reference's full [B*R, L]: every real role takes its own row, every padded slot
+    the shared last row.  Backward: a real role's gradient goes to its row; the shared row receives the SUM of all padded slots'
+    gradients (zero whenever the loss ignores padded targets, as the reference's `ignore_index` does -- model.py:196-199 -- but exact
+    in any case; fixed-order reduction, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, packed, packed_of_full, valid, pad_rows):
+        ctx.save_for_backward(valid, pad_rows)
+        ctx.rows = packed.shape[0]
+        return packed.index_select(0, packed_of_full)
+
+    @staticmethod
+    def backward(ctx, d_full):
+        valid, pad_rows = ctx.saved_tensors
+        d = torch.empty((ctx.rows, d_full.shape[1]), device=d_full.device, dtype=d_full.dtype)
+        torch.index_select(d_full, 0, valid, out=d[:-1])
+        if pad_rows.numel():
+            d[-1] = d_full.index_select(0, pad_rows).sum(0)
+        else:
+            d[-1].zero_()
+        return d, None, None, None
 
 
 class _ClassifierFunction(torch.autograd.Function):
@@ -829,6 +855,13 @@ class FCGGNN(nn.Module):
         self.overlap_backbones = None if env is None else env not in ("0", "")
         self._side_streams = {}
         self._noun_feat_cache = None
+        # packed role rows (see _nouns_from_features): None = automatic (noun paths of at least pack_roles_min_rows rows: one host
+        # synchronisation per forward is cheaper than the padded slots' GEMM rows from there on), True / False force it
+        env = os.environ.get("SR_PACK_ROLES")
+        self.pack_roles = None if env in (None, "", "auto") else env not in ("0",)
+        self.pack_roles_min_rows = int(os.environ.get("SR_PACK_ROLES_MIN_ROWS", "6144"))
+        self._pad_ok, self._pad_check_epoch = None, 0
+        self.register_load_state_dict_post_hook(lambda m, incompatible: setattr(m, "_pad_check_epoch", m._pad_check_epoch + 1))
         self.backbone_cu_share = int(os.environ.get("SR_BACKBONE_CU_SHARE", "2"))   # see forward(): 2 = each overlapped pass on half the CUs
         # one train-mode pass for both backbones while their (frozen) weights are identical -- see forward()
         self.share_identical_backbones = os.environ.get("SR_SHARE_BACKBONES", "1") not in ("0", "")
@@ -855,11 +888,52 @@ class FCGGNN(nn.Module):
         lin = seq[1]
         return _ClassifierFunction.apply(x, lin.weight, lin.bias, self._shadow, self._drop_seed(seq[0].p))
 
+    def _pack_plan(self, verbs, B, R):
+        """Packing of a batch's role rows (see sr_node_init_fwd in include/srhip.h): (offs int32 [B+1], rows, full row index of every
+        packed row, packed row of every full row, full row indices of the padded slots).  ONE host synchronisation (the number of
+        real roles sizes every tensor of the noun path); the noun backbone keeps the GPU busy on its own stream meanwhile."""
+        dev = verbs.device
+        counts = self.encoder.device_tables(dev)[2][verbs]
+        offs = torch.zeros(B + 1, device=dev, dtype=torch.int32)
+        offs[1:] = torch.cumsum(counts, 0)
+        real = (torch.arange(R, device=dev)[None, :] < counts[:, None]).reshape(-1)
+        valid = real.nonzero().squeeze(1)                                               # (the synchronisation)
+        rows = valid.numel()
+        packed_of_full = torch.full((B * R,), rows, device=dev, dtype=torch.int64)
+        packed_of_full[valid] = torch.arange(rows, device=dev)
+        pad_rows = (~real).nonzero().squeeze(1)
+        return offs, rows, valid, packed_of_full, pad_rows
+
+    def _pad_row_is_zero(self):
+        """The packed form relies on role_emb's padding row being exactly zero (nn.Embedding(padding_idx) creates it so and never
+        updates it; a state dict could carry anything).  Checked once per parameter storage / load."""
+        w = self.role_emb.weight
+        key = (w.data_ptr(), self._pad_check_epoch)
+        if self._pad_ok is None or self._pad_ok[0] != key:
+            self._pad_ok = (key, not bool((w.detach()[self.role_emb.padding_idx] != 0).any().item()))
+        return self._pad_ok[1]
+
+    def _use_packed(self, B, R):
+        if self.pack_roles is not None:
+            on = bool(self.pack_roles)
+        else:
+            on = B * R >= self.pack_roles_min_rows
+        return on and R > 1 and self._pad_row_is_zero()
+
     def _nouns_from_features(self, feat, verbs, batch_size):
         dev = feat.device
         role_table, adj_table, _ = self.encoder.device_tables(dev)
         verbs = verbs.to(device=dev, dtype=torch.int64).contiguous()
         R = self.encoder.get_max_role_count()
+        if self._use_packed(batch_size, R):
+            # Only the REAL roles' rows go through node init, the T GGNN steps and the classifier; all padded slots share one row
+            # (identical results: see sr_node_init_fwd).  imSitu verbs have 3.5 of 6 roles on average: 0.6 of the noun path's rows.
+            offs, rows, valid, packed_of_full, pad_rows = self._pack_plan(verbs, batch_size, R)
+            node = _NodeInitFunction.apply(feat, self.role_emb.weight, self.verb_emb.weight, verbs, role_table, offs, rows)
+            out = self.ggsnn.run(node, adj_table, verbs, R, False, offs=offs)
+            packed = self._classify(self.nouns_classifier, out)
+            logits = _ExpandRowsFunction.apply(packed, packed_of_full, valid, pad_rows)
+            return logits.reshape(batch_size, R, -1)
         node = _NodeInitFunction.apply(feat, self.role_emb.weight, self.verb_emb.weight, verbs, role_table)
         out = self.ggsnn.run(node, adj_table, verbs, R, False)                          # model.py:151
         logits = self._classify(self.nouns_classifier, out)                             # model.py:152

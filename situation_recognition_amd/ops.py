@@ -405,16 +405,26 @@ def avgpool(x):
     return y
 
 
-def node_init_fwd(feat, role_emb, verb_emb, verbs, role_table):
+def _check_offs(offs, B):
+    if offs is not None and (offs.dtype != torch.int32 or tuple(offs.shape) != (B + 1,) or not offs.is_cuda or not offs.is_contiguous()):
+        raise L.SrError("packed rows: offs must be a contiguous int32 [B+1] CUDA tensor")
+
+
+def node_init_fwd(feat, role_emb, verb_emb, verbs, role_table, offs=None, rows=None):
+    """`offs` int32 [B+1] + `rows` = offs[B] (known to the host): the packed form -- only real roles' rows plus ONE shared row for all
+    padded slots (row `rows`, zero), see sr_node_init_fwd."""
     require_gpu(feat, role_emb, verb_emb, verbs, role_table)
     B, D = feat.shape
     R = role_table.shape[1]
     if verbs.dtype != torch.int64 or role_table.dtype != torch.int32:
         raise L.SrError("verbs must be int64 and role_table int32")
-    node = torch.empty((B * R, D), device=feat.device, dtype=feat.dtype)
+    _check_offs(offs, B)
+    node = torch.empty((B * R if offs is None else rows + 1, D), device=feat.device, dtype=feat.dtype)
+    if offs is not None:
+        node[rows:].zero_()
     check(lib().sr_node_init_fwd(feat.data_ptr(), _f32(role_emb, "role_emb").data_ptr(), _f32(verb_emb, "verb_emb").data_ptr(),
                                  verbs.data_ptr(), role_table.data_ptr(), node.data_ptr(), B, R, D, dtype_code(feat.dtype),
-                                 stream()), "sr_node_init_fwd")
+                                 ptr(offs), stream()), "sr_node_init_fwd")
     return node
 
 
@@ -436,12 +446,13 @@ def _role_inverted_index(role_table, NR):
     return hit
 
 
-def node_init_bwd(dnode, feat, role_emb, verb_emb, verbs, role_table, d_role_emb, d_verb_emb):
+def node_init_bwd(dnode, feat, role_emb, verb_emb, verbs, role_table, d_role_emb, d_verb_emb, offs=None):
     """Writes d_role_emb [NR+1,D] and d_verb_emb [V,D] in full (deterministic: see sr_node_init_bwd)."""
     require_gpu(dnode, feat, role_emb, verb_emb, verbs, role_table, d_role_emb, d_verb_emb)
     B, D = feat.shape
     V, R = role_table.shape
     NR = role_emb.shape[0] - 1
+    _check_offs(offs, B)
     if tuple(d_role_emb.shape) != (NR + 1, D) or tuple(d_verb_emb.shape) != (V, D) or verb_emb.shape[0] != V:
         raise L.SrError("node_init_bwd: gradient / table shapes do not match")
     sorted_verbs, order = torch.sort(verbs, stable=True)            # (no host synchronisation: bincount would need one)
@@ -452,19 +463,21 @@ def node_init_bwd(dnode, feat, role_emb, verb_emb, verbs, role_table, d_role_emb
     check(lib().sr_node_init_bwd(dnode.data_ptr(), feat.data_ptr(), role_emb.data_ptr(), verb_emb.data_ptr(), order.data_ptr(),
                                  seg.data_ptr(), role_table.data_ptr(), inv_ptr.data_ptr(), inv_slot.data_ptr(),
                                  scratch.data_ptr(), _f32(d_role_emb, "d_role_emb").data_ptr(),
-                                 _f32(d_verb_emb, "d_verb_emb").data_ptr(), B, R, D, V, NR, dtype_code(feat.dtype), stream()),
+                                 _f32(d_verb_emb, "d_verb_emb").data_ptr(), B, R, D, V, NR, dtype_code(feat.dtype), ptr(offs), stream()),
           "sr_node_init_bwd")
 
 
-def aggregate(h, adj_table, verbs, R, transpose=False, add=None, out=None):
+def aggregate(h, adj_table, verbs, R, transpose=False, add=None, out=None, offs=None):
+    """`offs` int32 [B+1]: packed role rows (h has offs[B] + 1 rows: the real roles' rows and the shared padded-slot row)."""
     require_gpu(h, adj_table, verbs, add)
     M, D = h.shape
-    B = M // R
+    B = M // R if offs is None else verbs.shape[0]
+    _check_offs(offs, B)
     out = torch.empty_like(h) if out is None else out
     nbytes = (2 + (add is not None)) * M * D * h.element_size() + 4 * B * R * R
     check(_timed("aggregate", 0, nbytes,
                  lambda: lib().sr_ggnn_aggregate(h.data_ptr(), _f32(adj_table, "adj_table").data_ptr(), verbs.data_ptr(), ptr(add),
-                                                 out.data_ptr(), B, R, D, int(transpose), dtype_code(h.dtype), stream())),
+                                                 out.data_ptr(), B, R, D, int(transpose), dtype_code(h.dtype), ptr(offs), stream())),
           "sr_ggnn_aggregate")
     return out
 
