@@ -13,6 +13,8 @@
 // The Gram sum runs over the pixel index m, so both MFMA operands are the SAME transposed fragment of x
 // ("8 consecutive pixels of one channel per lane"): it is read straight out of the row-major LDS image with
 // ds_read_b64_tr_b16, and because A and B use one k-order any pixel permutation inside a fragment is harmless.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
   static_assert(!TN || (TWO && P == 256), "TN GEMM mode: separate 256-column panels");
   static_assert(!FUSE || (!TWO && !TN), "fused BatchNorm apply: single panel only");
   constexpr int SPS = (FUSE && KEEP) ? 2 : 0;     // stores per lane and stage (KEEP: the normalised stage is written back over x)
+  constexpr bool SPLIT = FUSE && !KEEP;           // see the L section of the loop
   constexpr int KS = 256 / P, RG = P / 32, FB = P / 16, SR = 32 * KS;
   constexpr int CPRW = P / 8, ROWB = P * 2, STAGE = SR * ROWB;
   constexpr int NPAN = TWO ? 2 : 1, NS = TWO ? 4 : 8, IPS = 2 * NPAN;
@@ -67,7 +70,8 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
   static_assert(STAGE == 16384, "stage");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it stays in SGPRs
   // SYM (one panel, G = x^T x): only the 16 x 16 blocks on or below the block diagonal of the stored matrix -- B-side fragment
   // j >= A-side fragment -- are computed (136 of 256 fragment products at P = 256) and stored; the reduction mirrors them.  A
   // wave's two A-side fragments are rg and FA-1-rg (not 2rg, 2rg+1), so that every wave has FA+1 products per stage: the M
@@ -85,32 +89,39 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
   const long r1 = min(p.M, r0 + p.rows_per_wg);
   const int nst = (int)((r1 - r0 + SR - 1) / SR);
 
-  // ---- loader: chunk q = j*512 + tid of a stage; LDS position q*16, data chunk (q % CPRW) ^ swz(row)
-  long src_off[2], src_offb[2];
-  int src_row[2];
+  // ---- loader (round 3: buffer loads with SCALAR stage offsets).  Chunk q = j*512 + tid of a stage goes to LDS position q*16 and
+  // holds data chunk (q % CPRW) ^ swz(row) of stage row q / CPRW.  The slice is one buffer descriptor (base = its first row and
+  // the panel's first column, num_records = up to the end of its last row's panel segment); a lane's byte offset inside a stage
+  // is loop invariant (vo), the stage's offset is a scalar that advances by SR rows.  Rows past the slice and whole stages past
+  // its end fall outside num_records: the load then writes ZEROS into LDS (checked on hardware, tools/ubench/buffer_lds_oob.hip),
+  // so the issue count per stage is fixed and nothing is selected per lane.  The first form of this loader -- global_load_lds
+  // with a 64-bit per-lane pointer, a zero page for the rows past the end, per-fragment exec-mask branches for the SYM skip
+  // -- spent 96 scalar + 50 vector instructions per stage on bookkeeping: the L section of the ping-pong loop was 3x its M
+  // section and the sweep ran at 3.1-3.8 TB/s with the matrix pipe 30 % busy (profiles/r03/pmc_gram_reduce.txt).
+  const int pitchA = (int)(p.ldx * 2), pitchB = TN ? (int)(p.ldb * 2) : pitchA;
+  int vo[2], vob[2], src_row[2];
+  long src_off[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int q = j * 512 + tid, row = q / CPRW, slot = q % CPRW;
     src_row[j] = row;
-    src_off[j] = (long)row * p.ldx + ((slot ^ gram_swz<P>(row)) * 8);
-    src_offb[j] = TN ? (long)row * p.ldb + ((slot ^ gram_swz<P>(row)) * 8) : src_off[j];
+    src_off[j] = (long)row * p.ldx + ((slot ^ gram_swz<P>(row)) * 8);        // (elements; KEEP's write-back address)
+    vo[j] = row * pitchA + ((slot ^ gram_swz<P>(row)) * 16);
+    vob[j] = row * pitchB + ((slot ^ gram_swz<P>(row)) * 16);
   }
+  const long nrows = r1 - r0;
+  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + r0 * p.ldx + colA0), 0,
+                                                                          (int)((nrows - 1) * pitchA + P * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(TN ? p.xb + r0 * p.ldb + colB0 : p.x + r0 * p.ldx + colB0), 0, (int)((nrows - 1) * pitchB + P * 2), 0x00020000);
   auto issue = [&](int st) {
     char* dst = smem + (st % NS) * SLOT + wave * 1024;
-    const long R = r0 + (long)st * SR;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const bool ok = st < nst && R + src_row[j] < r1;
-      const bf16_t* base = p.x + R * p.ldx + src_off[j];
-      const bf16_t* sa = ok ? base + colA0 : (const bf16_t*)p.zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
-                                       (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
-      if (TWO) {
-        const bf16_t* baseb = TN ? p.xb + R * p.ldb + src_offb[j] : base;
-        const bf16_t* sb = ok ? baseb + colB0 : (const bf16_t*)p.zero;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
-                                         (__attribute__((address_space(3))) void*)(dst + STAGE + j * 8192), 16, 0, 0);
-      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, vo[j], st * (SR * pitchA), 0, 0);
+      if (TWO)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (__attribute__((address_space(3))) void*)(dst + STAGE + j * 8192), 16, vob[j],
+                                                 st * (SR * pitchB), 0, 0);
     }
   };
 
@@ -126,21 +137,26 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
     }
     __syncthreads();
   }
-  auto normalise = [&](int st) {
+  // (scale / shift of this lane's 8 channels: loop-carried registers -- 16 of them; the round-2 form re-read them from LDS in every
+  //  call because the kernel was at 214 registers; the scalar loader of round 3 freed ~30)
+  sr_f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, h0 = s0, h1 = s0;
+  if (FUSE) {
+    s0 = *reinterpret_cast<const sr_f32x4*>(lds_sc + c8); s1 = *reinterpret_cast<const sr_f32x4*>(lds_sc + c8 + 4);
+    h0 = *reinterpret_cast<const sr_f32x4*>(lds_sc + P + c8); h1 = *reinterpret_cast<const sr_f32x4*>(lds_sc + P + c8 + 4);
+  }
+  auto normalise_half = [&](int st, int j) {
     char* img = smem + (st % NS) * SLOT + wave * 1024 + lane * 16;
     const long R = r0 + (long)st * SR;
-    const sr_f32x4 s0 = *reinterpret_cast<const sr_f32x4*>(lds_sc + c8), s1 = *reinterpret_cast<const sr_f32x4*>(lds_sc + c8 + 4);
-    const sr_f32x4 h0 = *reinterpret_cast<const sr_f32x4*>(lds_sc + P + c8), h1 = *reinterpret_cast<const sr_f32x4*>(lds_sc + P + c8 + 4);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const bool ok = st < nst && R + src_row[j] < r1;
-      const sr_u32x4 n = sr_affine_relu_chunk(*reinterpret_cast<const sr_u32x4*>(img + j * 8192), s0, s1, h0, h1);
-      const uint4 v = ok ? make_uint4(n[0], n[1], n[2], n[3]) : make_uint4(0u, 0u, 0u, 0u);       // rows past the slice stay zero
-      *reinterpret_cast<uint4*>(img + j * 8192) = v;
-      // KEEP: exactly one store per piece (rows past the slice: the trash page), so that the vmcnt arithmetic below holds
-      if (KEEP) *reinterpret_cast<uint4*>(ok ? (char*)(const_cast<bf16_t*>(p.x) + R * p.ldx + src_off[j]) : (char*)p.trash + tid * 16) = v;
-    }
+    const bool ok = st * SR + src_row[j] < (int)nrows;                                              // (implies st < nst)
+    const sr_u32x4 n = sr_affine_relu_chunk(*reinterpret_cast<const sr_u32x4*>(img + j * 8192), s0, s1, h0, h1);
+    const sr_u32x4 vz = ok ? n : sr_u32x4{0u, 0u, 0u, 0u};                                          // rows past the slice stay zero
+    // (inline asm: behind a plain LDS store hipcc puts `s_waitcnt vmcnt(0)` -- the store might alias a pending LDS-DMA -- which
+    //  drains the ring once per stage, like the transposed reads below; the caller's `s_waitcnt lgkmcnt(0)` covers it)
+    asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(uintptr_t)(img + j * 8192)), "v"(vz) : "memory");
+    // KEEP: exactly one store per piece (rows past the slice: the trash page), so that the vmcnt arithmetic below holds
+    if (KEEP) *reinterpret_cast<uint4*>(ok ? (char*)(const_cast<bf16_t*>(p.x) + R * p.ldx + src_off[j]) : (char*)p.trash + tid * 16) = make_uint4(vz[0], vz[1], vz[2], vz[3]);
   };
+  auto normalise = [&](int st) { normalise_half(st, 0); normalise_half(st, 1); };
 
   // ---- transposed-read addressing: lane (g = lane>>4, q = (lane>>2)&3, pp = lane&3) supplies row 8g+q (+4 for the
   // second read), 8-byte piece pp of the block's 32-byte row segment
@@ -149,13 +165,21 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
   const int fh = gram_swz<P>(row0) >> 1;
   const int rd_base = row0 * ROWB + 16 * (pp >> 1) + 8 * (pp & 1);
 
+  // The transposed reads are INLINE ASM on purpose: behind the builtin (__builtin_amdgcn_ds_read_tr16_b64) hipcc (ROCm 7.2) puts an
+  // `s_waitcnt vmcnt(0)` in front of the first read of every stage -- it treats the read as a possible reader of the pending LDS-DMA
+  // writes -- which drains the whole 7-stage ring once per stage: the waves spent 40-50 % of their cycles parked there (SQ_WAIT_ANY,
+  // profiles/r03/pmc_gram_reduce.txt) and the sweep was latency-bound.  The asm form is invisible to that pass; the ring is retired by
+  // the counted gram_wait_vm<> waits alone.  Consequence: the compiler does not count these reads in lgkmcnt either, so every
+  // fragment is pinned behind the explicit `s_waitcnt lgkmcnt(0)` of the L section with frag_ready() before an MFMA may use it.
   auto frag = [&](const char* img, int cb) -> bf16x8_t {
-    const char* a = img + rd_base + 32 * (cb ^ fh);
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a);
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a + 4 * ROWB));
+    const unsigned a = (unsigned)(uintptr_t)(img + rd_base + 32 * (cb ^ fh));        // (LDS offset: low 32 bits of the flat address)
+    s16x4_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(4 * ROWB));
     const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, v);
   };
+  auto frag_ready = [&](bf16x8_t& f) { asm volatile("" : "+v"(f)); };
 
   f32x4_t acc[2][FB], cs[2];
 #pragma unroll
@@ -168,7 +192,7 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
-  // ---- pipeline: NS-1 stages in flight; issues past the slice's end read the zero page so the count stays fixed.
+  // ---- pipeline: NS-1 stages in flight; issues past the slice's end fall outside the descriptor (zeros) so the count stays fixed.
   // The two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run half a stage apart, as in the GEMM kernel: an L
   // section (all transposed fragment reads of the stage, the DMA of stage it+NS-1, wait for the reads) and an M section
   // (the stage's MFMAs, no memory instruction), each closed by a barrier; group 1 starts one barrier late, so one wave of
@@ -177,62 +201,100 @@ __global__ __launch_bounds__(512, 1) void gram_kernel(const GramArgs p) {
   // G0.B2(it) = G1.B1(it).  Stage it is read in L(it); every wave has waited for its own pieces of it before the last
   // instance both groups pass ahead of that (G0: end of M(it-1); G1: in L(it-1)); the slot refilled in L(it) is the one
   // stage it-1 was read from, drained (lgkmcnt 0) by both groups before their B1(it-1).
+  // SYM: the loop is instantiated once per row group (RGV compile time, selected by a scalar switch), so which fragment products
+  // exist is known to the compiler: no predication inside the stage.
   const int grp = wave >> 2;
+  auto run = [&](auto RGC) {
+    constexpr int RGV = decltype(RGC)::value;
+    const int f0 = SYM ? RGV : fa0, f1 = SYM ? FA - 1 - RGV : fa1;
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s) issue(s);
-  gram_wait_vm<(NS - 2) * IPS>();        // my pieces of stage 0
-  if (FUSE) {
-    // a stage is normalised by its loaders right after their own wait for it, at the end of an M section (the fragment
-    // registers are dead there): group 0 does stage it+1 there, group 1 -- whose wait sits a barrier earlier -- stage it+2
-    normalise(0);                                       // (+2 stores, younger than every DMA so far)
-    if (grp == 1) { gram_wait_vm<(NS - 3) * IPS + SPS>(); normalise(1); }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();
-  for (int it = 0; it < nst; ++it) {
-    const char* imgA = smem + (it % NS) * SLOT;
-    const char* imgB = TWO ? imgA + STAGE : imgA;
-    bf16x8_t a[2], b[FB];
-    a[0] = frag(imgA, fa0);
-    a[1] = frag(imgA, fa1);
-#pragma unroll
-    for (int j = 0; j < FB; ++j)
-      if (!SYM || j >= fa0) b[j] = frag(imgB, j);
-    issue(it + NS - 1);                  // refills the slot stage it-1 used
-    if (!FUSE && grp == 1) gram_wait_vm<(NS - 2) * IPS>();      // my pieces of stage it+1
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();        // B1
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int j = 0; j < FB; ++j) {
-      if (!SYM || j >= fa0) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[j], acc[0][j], 0, 0, 0);
-      if (!SYM || j >= fa1) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[j], acc[1][j], 0, 0, 0);
-    }
-    if (!TN) {
-      cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ones, cs[0], 0, 0, 0);
-      cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ones, cs[1], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+    gram_wait_vm<(NS - 2) * IPS>();        // my pieces of stage 0
     if (FUSE) {
-      // vmcnt counts the 2 stores of every normalise() too, in issue order with the DMAs (one DMA pair per L section, one
-      // store pair per M section): younger than the pieces of stage it+1 are 6 DMA stages + 6 store pairs (group 0),
-      // than those of stage it+2 5 + 5 (group 1).  In the first iterations fewer store pairs have been issued yet, so
-      // FEWER operations are younger: there the count without any stores is used (stricter, always safe).
-      if (grp == 0) {
-        if (it >= NS - 3) gram_wait_vm<(NS - 2) * (IPS + SPS)>(); else gram_wait_vm<(NS - 2) * IPS>();
-        normalise(it + 1);
-      } else {
-        if (it >= NS - 5) gram_wait_vm<(NS - 3) * (IPS + SPS)>(); else gram_wait_vm<(NS - 3) * IPS>();
-        normalise(it + 2);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my LDS writes are in place before the barrier
-    } else if (grp == 0) {
-      gram_wait_vm<(NS - 2) * IPS>();    // my pieces of stage it+1
+      // a stage is normalised by its loaders right after their own wait for it, at the end of an M section (the fragment
+      // registers are dead there): group 0 does stage it+1 there, group 1 -- whose wait sits a barrier earlier -- stage it+2
+      normalise(0);                                       // (+2 stores, younger than every DMA so far)
+      if (grp == 1) { gram_wait_vm<(NS - 3) * IPS + SPS>(); normalise(1); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();        // B2
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < nst; ++it) {
+      const char* imgA = smem + (it % NS) * SLOT;
+      const char* imgB = TWO ? imgA + STAGE : imgA;
+      bf16x8_t a[2], b[FB];
+      a[0] = frag(imgA, f0);
+      a[1] = frag(imgA, f1);
+#pragma unroll
+      for (int j = 0; j < FB; ++j)
+        if (!SYM || (j > f0 && j != f1)) b[j] = frag(imgB, j);      // (one panel: B-side fragments f0, f1 ARE the A-side fragments)
+      issue(it + NS - 1);                  // refills the slot stage it-1 used
+      if (!FUSE && grp == 1) gram_wait_vm<(NS - 2) * IPS>();      // my pieces of stage it+1
+      if (SPLIT) {
+        // no write-back (no stores in the vmcnt order): the normalisation of a stage is split over the L and the M section --
+        // chunk 0 here, behind the fragment reads (their latency covers it), chunk 1 behind the MFMAs -- so that the two sections
+        // the barriers pair (one group's L beside the other's M) are about equally long.  Group 0 works on stage it+1, group 1,
+        // whose sections sit half a stage later, on stage it+2; a lane only ever touches the chunks it loaded itself.
+        if (grp == 0) { gram_wait_vm<(NS - 2) * IPS>(); normalise_half(it + 1, 0); }
+        else { gram_wait_vm<(NS - 3) * IPS>(); normalise_half(it + 2, 0); }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      frag_ready(a[0]); frag_ready(a[1]);
+#pragma unroll
+      for (int j = 0; j < FB; ++j) {
+        if (SYM && j == f0) b[j] = a[0];                           // (register copies only AFTER the wait: the compiler does not know the
+        else if (SYM && j == f1) b[j] = a[1];                      //  asm reads are pending)
+        else if (!SYM || j > f0) frag_ready(b[j]);
+      }
+      __builtin_amdgcn_s_barrier();        // B1
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < FB; ++j) {
+        if (!SYM || j >= f0) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[j], acc[0][j], 0, 0, 0);
+        if (!SYM || j >= f1) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[j], acc[1][j], 0, 0, 0);
+      }
+      if (!TN) {
+        cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], ones, cs[0], 0, 0, 0);
+        cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], ones, cs[1], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (SPLIT) {
+        normalise_half(grp == 0 ? it + 1 : it + 2, 1);           // (landed: waited for in this iteration's L section)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else if (FUSE) {
+        // vmcnt counts the 2 stores of every normalise() too, in issue order with the DMAs (one DMA pair per L section, one
+        // store pair per M section): younger than the pieces of stage it+1 are 6 DMA stages + 6 store pairs (group 0),
+        // than those of stage it+2 5 + 5 (group 1).  In the first iterations fewer store pairs have been issued yet, so
+        // FEWER operations are younger: there the count without any stores is used (stricter, always safe).
+        if (grp == 0) {
+          if (it >= NS - 3) gram_wait_vm<(NS - 2) * (IPS + SPS)>(); else gram_wait_vm<(NS - 2) * IPS>();
+          normalise(it + 1);
+        } else {
+          if (it >= NS - 5) gram_wait_vm<(NS - 3) * (IPS + SPS)>(); else gram_wait_vm<(NS - 3) * IPS>();
+          normalise(it + 2);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my LDS writes are in place before the barrier
+      } else if (grp == 0) {
+        gram_wait_vm<(NS - 2) * IPS>();    // my pieces of stage it+1
+      }
+      __builtin_amdgcn_s_barrier();        // B2
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  };
+  if constexpr (SYM) {
+    switch (rg) {
+      case 0: run(std::integral_constant<int, 0>{}); break;
+      case 1: run(std::integral_constant<int, 1>{}); break;
+      case 2: if constexpr (RG > 2) run(std::integral_constant<int, 2>{}); break;
+      case 3: if constexpr (RG > 2) run(std::integral_constant<int, 3>{}); break;
+      case 4: if constexpr (RG > 4) run(std::integral_constant<int, 4>{}); break;
+      case 5: if constexpr (RG > 4) run(std::integral_constant<int, 5>{}); break;
+      case 6: if constexpr (RG > 4) run(std::integral_constant<int, 6>{}); break;
+      default: if constexpr (RG > 4) run(std::integral_constant<int, 7>{}); break;
+    }
+  } else {
+    run(std::integral_constant<int, 0>{});
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();
   gram_wait_vm<0>();                     // drain the padding DMAs before the workgroup's LDS goes away
 
   // ---- partial (slice, ks): lane holds D[a = 4g+r][b = lane&15]; stored transposed (G is used through the symmetric

@@ -18,6 +18,12 @@ def flat(r):
     return [x.clone() for x in r if torch.is_tensor(x)]
 
 
+def gm(part, C):
+    """the entries of Gram partials the kernels WRITE (block-lower triangle for C <= 256: the rest of the buffer is never touched)"""
+    valid = torch.cat([ops.gram_valid_mask(C).reshape(-1), torch.ones(C, dtype=torch.bool)]).to(part.device)
+    return part[:, valid]
+
+
 def screen(name, fn):
     ref = flat(fn())
     bad = 0
@@ -37,16 +43,19 @@ for B in (96, 768):
     bad += screen("B=%d 3x3 256->256 + stats" % B, lambda: ops.conv2d(x256, w33, 256, 3, 1, 1, want_stats=True))
     bad += screen("B=%d 1x1 256->1024 scale/shift/res/relu" % B, lambda: ops.conv2d(x256, w3, 1024, 1, 1, 0, bias=sh, escale=sc, res=x1024, relu=True))
     bad += screen("B=%d 1x1 1024->256 + stats" % B, lambda: ops.conv2d(x1024, w1, 256, 1, 1, 0, want_stats=True))
-    bad += screen("B=%d gram 256" % B, lambda: ops.gram(x256.view(-1, 256)))
+    bad += screen("B=%d gram 256" % B, lambda: gm(ops.gram(x256.view(-1, 256)), 256))
     s2, h2 = torch.rand(256, device=dev) + .5, torch.randn(256, device=dev) * .1
     def fused():
         y = x256.view(-1, 256).clone()
-        return y, ops.bn_apply_gram(y, s2, h2)
+        return y, gm(ops.bn_apply_gram(y, s2, h2), 256)
     bad += screen("B=%d bn_apply+gram 256" % B, fused)
+    bad += screen("B=%d bn_gram 256 (no write-back)" % B, lambda: gm(ops.bn_gram(x256.view(-1, 256), s2, h2), 256))
     x64 = t(B, 56, 56, 64); w64 = t(64, 9 * 64, scale=.05)
-    bad += screen("B=%d 3x3 64->64 (256x64 tiles)" % B, lambda: ops.conv2d(x64, w64, 64, 3, 1, 1, want_stats=True))
+    bad += screen("B=%d 3x3 64->64 (direct kernel, c3d.hip)" % B, lambda: ops.conv2d(x64, w64, 64, 3, 1, 1, want_stats=True))
     x128 = t(B, 28, 28, 128); w128 = t(128, 9 * 128, scale=.04)
     bad += screen("B=%d 3x3 128->128 (256x128 tiles)" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True))
+    bad += screen("B=%d gram 128 / bn_gram 128" % B, lambda: (gm(ops.gram(x128.view(-1, 128)), 128), gm(ops.bn_gram(x128.view(-1, 128), s2[:128].contiguous(), h2[:128].contiguous()), 128)))
+    bad += screen("B=%d gram 64 / bn_gram 64" % B, lambda: (gm(ops.gram(x64.view(-1, 64)), 64), gm(ops.bn_gram(x64.view(-1, 64), s2[:64].contiguous(), h2[:64].contiguous()), 64)))
 M = 36864
 n, h, W = t(M, 2048), t(M, 2048), t(2048, 2048, scale=.02)
 U = t(2048, 2048, scale=.02); b1, b2 = torch.randn(2048, device=dev), torch.randn(2048, device=dev)
