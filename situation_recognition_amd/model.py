@@ -587,6 +587,7 @@ class _Shadow:
         key = (id(p), dtype, transposed, pad_to)
         sig = (p.data_ptr(), p._version)
         hit = self._c.get(key)
+        cur = torch.cuda.current_stream(p.device) if p.is_cuda else None
         if hit is None or hit[0] != sig:
             with torch.no_grad():
                 d = p.detach()
@@ -594,8 +595,15 @@ class _Shadow:
                     t = ops.transpose(d, out_dtype=dtype, pad_to=pad_to)
                 else:
                     t = d if dtype == torch.float32 else ops.cast(d, dtype)
-            hit = (sig, t)
+            ev = None
+            if cur is not None and t is not d:            # a copy made on `cur`: another stream must wait for it before reading
+                ev = torch.cuda.Event()
+                ev.record(cur)
+            hit = (sig, t, ev, cur)
             self._c[key] = hit
+        elif hit[2] is not None and cur != hit[3]:
+            cur.wait_event(hit[2])
+            hit[1].record_stream(cur)
         return hit[1]
 
 
@@ -862,6 +870,7 @@ class FCGGNN(nn.Module):
         self.pack_roles_min_rows = int(os.environ.get("SR_PACK_ROLES_MIN_ROWS", "6144"))
         self._pad_ok, self._pad_check_epoch = None, 0
         self.register_load_state_dict_post_hook(lambda m, incompatible: setattr(m, "_pad_check_epoch", m._pad_check_epoch + 1))
+        self.overlap_gt_branch = os.environ.get("SR_OVERLAP_GT", "1") not in ("0", "")     # see forward()
         self.backbone_cu_share = int(os.environ.get("SR_BACKBONE_CU_SHARE", "2"))   # see forward(): 2 = each overlapped pass on half the CUs
         # one train-mode pass for both backbones while their (frozen) weights are identical -- see forward()
         self.share_identical_backbones = os.environ.get("SR_SHARE_BACKBONES", "1") not in ("0", "")
@@ -884,9 +893,13 @@ class FCGGNN(nn.Module):
         self._drop_counter += 1
         return (self.drop_seed_base * 0x9E3779B1 + self._drop_counter * 0x85EBCA77) & (2 ** 63 - 1)
 
-    def _classify(self, seq, x):
+    _DRAW = object()         # "draw the dropout seed now" (the reference's call order: verb, predicted-verb nouns, gt-verb nouns)
+
+    def _classify(self, seq, x, seed=_DRAW):
         lin = seq[1]
-        return _ClassifierFunction.apply(x, lin.weight, lin.bias, self._shadow, self._drop_seed(seq[0].p))
+        if seed is FCGGNN._DRAW:
+            seed = self._drop_seed(seq[0].p)
+        return _ClassifierFunction.apply(x, lin.weight, lin.bias, self._shadow, seed)
 
     def _pack_plan(self, verbs, B, R):
         """Packing of a batch's role rows (see sr_node_init_fwd in include/srhip.h): (offs int32 [B+1], rows, full row index of every
@@ -920,7 +933,7 @@ class FCGGNN(nn.Module):
             on = B * R >= self.pack_roles_min_rows
         return on and R > 1 and self._pad_row_is_zero()
 
-    def _nouns_from_features(self, feat, verbs, batch_size):
+    def _nouns_from_features(self, feat, verbs, batch_size, seed=_DRAW):
         dev = feat.device
         role_table, adj_table, _ = self.encoder.device_tables(dev)
         verbs = verbs.to(device=dev, dtype=torch.int64).contiguous()
@@ -931,12 +944,12 @@ class FCGGNN(nn.Module):
             offs, rows, valid, packed_of_full, pad_rows = self._pack_plan(verbs, batch_size, R)
             node = _NodeInitFunction.apply(feat, self.role_emb.weight, self.verb_emb.weight, verbs, role_table, offs, rows)
             out = self.ggsnn.run(node, adj_table, verbs, R, False, offs=offs)
-            packed = self._classify(self.nouns_classifier, out)
+            packed = self._classify(self.nouns_classifier, out, seed)
             logits = _ExpandRowsFunction.apply(packed, packed_of_full, valid, pad_rows)
             return logits.reshape(batch_size, R, -1)
         node = _NodeInitFunction.apply(feat, self.role_emb.weight, self.verb_emb.weight, verbs, role_table)
         out = self.ggsnn.run(node, adj_table, verbs, R, False)                          # model.py:151
-        logits = self._classify(self.nouns_classifier, out)                             # model.py:152
+        logits = self._classify(self.nouns_classifier, out, seed)                       # model.py:152
         return logits.reshape(batch_size, R, -1)                                        # model.py:155
 
     # -- reference surface
@@ -944,9 +957,9 @@ class FCGGNN(nn.Module):
         feat = self.convnet_nouns(img)
         return self._nouns_from_features(feat, gt_verb, batch_size)
 
-    def _verb_from_features(self, feat, batch_size):
+    def _verb_from_features(self, feat, batch_size, seed=_DRAW):
         out = self.ggsnn.run(feat.reshape(batch_size, -1), None, None, 1, True)
-        return self._classify(self.verb_classifier, out)
+        return self._classify(self.verb_classifier, out, seed)
 
     def predict_verb(self, img, batch_size):                                            # model.py:158-168
         return self._verb_from_features(self.convnet_verbs(img), batch_size)
@@ -979,18 +992,46 @@ class FCGGNN(nn.Module):
             # the first one's last round of tiles drains -- 2 x 588 row tiles of a 768-image layer3 launch are 4.6 of 5 rounds on
             # 128 CUs each, not 2 x (2.3 of 3) rounds on 256.
             prev = ops.set_cu_share(self.backbone_cu_share)
+            gt_early = None
             try:
                 with torch.cuda.stream(side):
                     feat = self.convnet_nouns(img, bn_updates=2, prepped=prepped)
+                    feat_ready = side.record_event()
                 img.record_stream(side)
                 if prepped is not None:
                     prepped[0].record_stream(side)
                 feat_v = self.convnet_verbs(img, prepped=prepped)
             finally:
                 ops.set_cu_share(prev)
-            pred_verb = self._verb_from_features(feat_v, batch_size)
-            main.wait_stream(side)
+            R = self.encoder.get_max_role_count()
+            if self.overlap_gt_branch and not self._use_packed(batch_size, R):
+                # Small per-GPU batches: a GGNN GEMM of 768 x 6 rows is 144 tiles on 256 CUs.  The ground-truth-verb noun branch needs
+                # only the noun features and gt_verb, so it is queued on the side stream right behind the noun backbone and runs BESIDE
+                # the verb path and the predicted-verb branch on the main stream.  (With packed role rows -- large batches, whose
+                # launches fill the chip alone -- the branch starts with a host synchronisation and stays on the main stream.)
+                for lin in (getattr(self.ggsnn, n) for n in self.ggsnn._ORDER):
+                    self.ggsnn._shadow.get(lin.weight, self.dtype)               # storage-dtype copies exist before the streams fork
+                self._shadow.get(self.nouns_classifier[1].weight, self.dtype)
+                self._shadow.get(self.verb_classifier[1].weight, self.dtype)
+                side.wait_stream(main)
+                # (dropout seeds in the reference's call order -- verb, predicted-verb nouns, gt-verb nouns -- whatever the launch order)
+                seed_v, seed_p = self._drop_seed(self.verb_classifier[0].p), self._drop_seed(self.nouns_classifier[0].p)
+                seed_g = self._drop_seed(self.nouns_classifier[0].p)
+                with torch.cuda.stream(side):
+                    gt_early = self._nouns_from_features(feat, gt_verb, batch_size, seed_g)
+                gt_verb.record_stream(side)
+            else:
+                seed_v = seed_p = FCGGNN._DRAW
+            pred_verb = self._verb_from_features(feat_v, batch_size, seed_v)
+            main.wait_event(feat_ready)
             feat.record_stream(main)
+            pred_nouns = self._nouns_from_features(feat, torch.argmax(pred_verb, 1), batch_size, seed_p)
+            if gt_early is not None:
+                main.wait_stream(side)
+                gt_early.record_stream(main)
+                return pred_verb, pred_nouns, gt_early
+            main.wait_stream(side)
+            return pred_verb, pred_nouns, self._nouns_from_features(feat, gt_verb, batch_size)
         else:
             pred_verb = self.predict_verb(img, batch_size)
             feat = self.convnet_nouns(img, bn_updates=2)
