@@ -303,19 +303,22 @@ def main():
             return e
 
         conv_tags = ["conv1x1", "conv3x3", "conv7x7", "conv3x3_fp8"]
-        head = entry(conv_tags, "mfma", "backbone convolutions, both passes, incl. statistics-only launches: conv_igemm_v3_kernel (3x3, reduce 1x1, downsample), conv3x3_c64_kernel (layer1 3x3), conv1x1_ws_kernel (output-heavy 1x1), stem_conv_kernel + stem_pool_kernel (7x7 stem)")
+        head = entry(conv_tags, "mfma", "backbone convolutions, both passes, incl. statistics-only launches: conv_igemm_v3_kernel (3x3, reduce 1x1, downsample), conv3x3_c64_kernel / conv3x3_c128_kernel (layer1 / layer2 3x3, direct, BatchNorm of their input applied on load), conv1x1_ws_kernel (output-heavy 1x1), stem_conv_kernel + stem_pool_kernel (7x7 stem)")
         hbm_view = entry(conv_tags, "hbm", "backbone convolutions")
         # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately on this exact
         # command: profiles/conv_traffic.json records them with the gfx950 corrections); null for any other configuration
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", "conv_traffic.json")))
             c = t["config"]
-            if (c["backbone"], c["per_gpu_batch"], c["dtype"], c["res"]) == (args.backbone, B, args.dtype, args.res):
+            if (c["backbone"], c["per_gpu_batch"], c["dtype"], c["res"]) == (args.backbone, B, args.dtype, args.res) and not args.fp8:
                 traffic = round(t["hbm_bytes_per_launch"])
+                traffic_source = ("RECORDED constant, not measured in this run: profiles/conv_traffic.json = HBM bytes per convolution launch from "
+                                  "separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command (FETCH_SIZE x2 on gfx950), "
+                                  "collected by tools/collect_profiles.sh; " + str(t.get("source", "")))
         except (OSError, KeyError, ValueError):
             pass
-        by = [entry(["conv3x3"], "mfma", "3x3 convolutions: conv_igemm_v3_kernel (128-512 channels) + conv3x3_c64_kernel (layer1, direct)"),
+        by = [entry(["conv3x3"], "mfma", "3x3 convolutions: conv_igemm_v3_kernel (256 / 512 channels, stride-2 layers) + conv3x3_c64_kernel, conv3x3_c128_kernel (layer1, layer2: direct, input BatchNorm on load)"),
               entry(["conv3x3_fp8"], "mfma", "conv3x3_fp8_kernel (e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4; peak = dense fp8)"), 
               entry(["conv1x1"], "hbm", "1x1 convolutions: conv_igemm_v3_kernel (reduce, downsample) + conv1x1_ws_kernel (expansion + BN + residual + ReLU)"),
               entry(["conv7x7"], "mfma", "7x7 stem: stem_conv_kernel (statistics pass) + stem_pool_kernel (conv + BN + ReLU + max-pool); FLOPs counted once"),
@@ -326,7 +329,7 @@ def main():
               entry(["gemm_tn"], "mfma", "gram_kernel<256,true,true> TN weight gradients"),
               entry(["aggregate", "gru_bwd"], "hbm", "GGNN step non-GEMM kernels: aggregate_kernel, gru_bwd1/2_kernel (SURVEY 8d: 11*M*D*s per step "
                                                       "if the forward gates were standalone; they are fused into the gate GEMMs)")]
-        out["roofline"] = dict(head, traffic=traffic, alg_bytes_per_launch=hbm_view["alg_bytes_per_launch"],
+        out["roofline"] = dict(head, traffic=traffic, traffic_source=traffic_source, alg_bytes_per_launch=hbm_view["alg_bytes_per_launch"],
                                hbm_view={k: hbm_view[k] for k in ("achieved", "peak", "unit", "frac")},
                                by_kernel=[e for e in by if e is not None])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -298,7 +298,7 @@ def _stats_close(stats, ref):
     assert float(((s2 - r2).abs() / r2).max()) < 1e-4
 
 
-@pytest.mark.parametrize("Cin,Cout,k,H,B,want_cfg", [(128, 128, 3, 28, 512, 2),       # layer2's 3x3 (7 per pass)
+@pytest.mark.parametrize("Cin,Cout,k,H,B,want_cfg", [(128, 128, 3, 24, 700, 2),       # a 128-channel 3x3 the direct kernel does not serve (24 x 24)
                                                      (512, 128, 1, 28, 512, 2),       # layer2's reduce conv (7 per pass)
                                                      (256, 64, 1, 56, 160, 1),        # layer1's reduce conv (2 per pass)
                                                      (64, 64, 1, 56, 160, 1)])        # layer1.0.conv1
@@ -307,7 +307,7 @@ def test_narrow_tile_kernels_at_multi_tile_production_shapes(ops, Cin, Cout, k, 
     (raw bf16 output + running BatchNorm partial sums across the 3+ tiles a workgroup walks -- the tile-to-tile ring hand-over),
     statistics-only form and eval form (bias + ReLU), against the fp32 im2col matmul of the bf16-rounded operands."""
     M = B * H * H
-    assert cfg(ops, M, Cout) == want_cfg == cfg(ops, 6144 * H * H, Cout)
+    assert cfg(ops, M, Cout) == want_cfg == cfg(ops, 6144 * 28 * 28 if H == 24 else 6144 * H * H, Cout)
     pad = k // 2
     assert ops.conv_route(B, H, H, Cin, Cout, k, 1, pad, want_stats=True) == want_cfg
     slots = 2 * torch.cuda.get_device_properties(0).multi_processor_count
@@ -388,3 +388,54 @@ def test_generic_residual_epilogue_512_2048_and_stride2_downsample(ops):
     close(y.view(M, Cout), want, k=2.0)
     ye = ops.conv2d(x, pack_w(w), Cout, 1, 2, 0, bias=beta)                  # eval form of the downsample: bias only
     close(ye.view(M, Cout), conv + beta)
+
+
+@pytest.mark.parametrize("B", [1, 3, 37, 300, 1100])
+def test_conv3x3_128_128_direct_kernel(ops, B):
+    """layer2's 3x3 (7 launches per pass) on the direct-convolution kernel (csrc/c3d128.hip: four image rows per tile, patch staged
+    once, every wave streaming its own 32 weight rows through a private LDS ring): train-mode form (raw output + BatchNorm partial
+    sums; batches from less than one tile per workgroup to 30 tiles per workgroup, so the weight ring wraps across tiles),
+    statistics-only form and eval form (bias + ReLU) against F.conv2d in fp32 on the bf16-rounded operands; bit-reproducible."""
+    from situation_recognition_amd import _lib
+    Cc, H = 128, 28
+    M = B * H * H
+    assert ops.conv_route(B, H, H, Cc, Cc, 3, 1, 1, want_stats=True) == _lib.ROUTE_C3D128 == ops.conv_route(6144, H, H, Cc, Cc, 3, 1, 1, want_stats=True)
+    assert ops.conv_route(B, H, H, Cc, Cc, 3, 1, 1, bias=True, relu=True) == _lib.ROUTE_C3D128
+    x = F.relu(rnd(B, H, H, Cc, seed=B)).to(BF)
+    w = rnd(Cc, Cc, 3, 3, seed=B + 1, scale=(Cc * 9) ** -0.5)
+    y, stats = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, want_stats=True)
+    assert stats.shape[0] == min(B * 7, torch.cuda.get_device_properties(0).multi_processor_count)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1).reshape(M, Cc)
+    close(y.view(M, Cc), ref)
+    _stats_close(stats, ref)
+    st2 = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, stats_only=True)
+    assert torch.equal(st2, stats)
+    bias = 0.3 * torch.randn(Cc, device="cuda")
+    y3 = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, bias=bias, relu=True)
+    close(y3.view(M, Cc), F.relu(ref + bias))
+    y4 = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1)
+    assert torch.equal(y4, y)
+    for _ in range(3):                                 # bit-reproducible (fixed summation order, no atomics)
+        yb, sb = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, want_stats=True)
+        assert torch.equal(yb, y) and torch.equal(sb, stats)
+
+
+@pytest.mark.parametrize("B", [2, 37, 600])
+def test_direct_128_3x3_normalises_its_input_on_load(ops, B):
+    """bn1 -> relu -> conv2 of a layer2 bottleneck without the normalised tensor: the 128-channel direct kernel applies scale / shift +
+    ReLU to the NEXT tile's patch in LDS while the current tile multiplies (pad pixels and the rows above / below the image stay
+    zero: the convolution pads the NORMALISED tensor).  Output and BatchNorm partial sums bit-identical to the same kernel on the
+    tensor bn_apply wrote, and within bf16 rounding of the fp32 reference."""
+    Cc, H = 128, 28
+    y1 = rnd(B, H, H, Cc, seed=B + 3)
+    sc, sh = 0.5 + torch.rand(Cc, device="cuda"), 0.3 * torch.randn(Cc, device="cuda") + 0.2     # (relu(shift) != 0 on the pads if transformed)
+    w = rnd(Cc, Cc, 3, 3, seed=B + 4, scale=(Cc * 9) ** -0.5)
+    assert ops.conv_in_affine_supported(y1, Cc, 3, 1, 1, res=None, relu=False, want_stats=True)
+    lazy, st_l = ops.conv2d(y1, pack_w(w), Cc, 3, 1, 1, want_stats=True, in_affine=(sc, sh))
+    z1 = ops.bn_apply(y1, sc, sh, relu=True)
+    eager, st_e = ops.conv2d(z1, pack_w(w), Cc, 3, 1, 1, want_stats=True)
+    assert torch.equal(lazy, eager) and torch.equal(st_l, st_e)
+    ref = F.conv2d(F.relu(y1.float() * sc + sh).to(BF).float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1)
+    close(lazy.view(-1, Cc), ref.reshape(-1, Cc))
+    with pytest.raises(Exception):                                     # eval form (bias + ReLU): not served with an input affine
+        ops.conv2d(y1, pack_w(w), Cc, 3, 1, 1, bias=sh, relu=True, in_affine=(sc, sh))

@@ -53,7 +53,10 @@ for B in (96, 768):
     x64 = t(B, 56, 56, 64); w64 = t(64, 9 * 64, scale=.05)
     bad += screen("B=%d 3x3 64->64 (direct kernel, c3d.hip)" % B, lambda: ops.conv2d(x64, w64, 64, 3, 1, 1, want_stats=True))
     x128 = t(B, 28, 28, 128); w128 = t(128, 9 * 128, scale=.04)
-    bad += screen("B=%d 3x3 128->128 (256x128 tiles)" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True))
+    bad += screen("B=%d 3x3 128->128 @28 (direct kernel, c3d128.hip)" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True))
+    bad += screen("B=%d 3x3 128->128 @28 direct, BN on load" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True, in_affine=(s2[:128].contiguous(), h2[:128].contiguous())))
+    x128b = t(B, 24, 24, 128)
+    bad += screen("B=%d 3x3 128->128 @24 (256x128 tiles)" % B, lambda: ops.conv2d(x128b, w128, 128, 3, 1, 1, want_stats=True))
     bad += screen("B=%d gram 128 / bn_gram 128" % B, lambda: (gm(ops.gram(x128.view(-1, 128)), 128), gm(ops.bn_gram(x128.view(-1, 128), s2[:128].contiguous(), h2[:128].contiguous()), 128)))
     bad += screen("B=%d gram 64 / bn_gram 64" % B, lambda: (gm(ops.gram(x64.view(-1, 64)), 64), gm(ops.bn_gram(x64.view(-1, 64), s2[:64].contiguous(), h2[:64].contiguous()), 64)))
 M = 36864
