@@ -992,7 +992,7 @@ class FCGGNN(nn.Module):
             # the first one's last round of tiles drains -- 2 x 588 row tiles of a 768-image layer3 launch are 4.6 of 5 rounds on
             # 128 CUs each, not 2 x (2.3 of 3) rounds on 256.
             prev = ops.set_cu_share(self.backbone_cu_share)
-            gt_early = None
+            gt_early, pinned = None, None
             try:
                 with torch.cuda.stream(side):
                     feat = self.convnet_nouns(img, bn_updates=2, prepped=prepped)
@@ -1013,6 +1013,10 @@ class FCGGNN(nn.Module):
                     self.ggsnn._shadow.get(lin.weight, self.dtype)               # storage-dtype copies exist before the streams fork
                 self._shadow.get(self.nouns_classifier[1].weight, self.dtype)
                 self._shadow.get(self.verb_classifier[1].weight, self.dtype)
+                if torch.is_grad_enabled():
+                    # the parameters' gradient-accumulation nodes are created by their first use in a graph and belong to the stream
+                    # current at that moment: make that the main stream (where their gradients will arrive), not the side stream
+                    pinned = [p.view_as(p) for p in self.parameters() if p.requires_grad]
                 side.wait_stream(main)
                 # (dropout seeds in the reference's call order -- verb, predicted-verb nouns, gt-verb nouns -- whatever the launch order)
                 seed_v, seed_p = self._drop_seed(self.verb_classifier[0].p), self._drop_seed(self.nouns_classifier[0].p)
@@ -1029,6 +1033,7 @@ class FCGGNN(nn.Module):
             if gt_early is not None:
                 main.wait_stream(side)
                 gt_early.record_stream(main)
+                pinned = None
                 return pred_verb, pred_nouns, gt_early
             main.wait_stream(side)
             return pred_verb, pred_nouns, self._nouns_from_features(feat, gt_verb, batch_size)
