@@ -22,6 +22,8 @@
 namespace {
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
 
 struct StemArgs {
   const bf16_t* x;          // [B, Hp, Wp, 4]
@@ -34,7 +36,8 @@ struct StemArgs {
 };
 
 constexpr int PROW = 304;                 // patch row: 38 pixels x 8 B
-constexpr int PBUF = 16384;               // one patch buffer (37 x 304 = 11 248 B, rounded up to 16 LDS-DMA pieces)
+constexpr int PBUF = 12288;               // one patch buffer (37 x 304 = 11 248 B = 11 LDS-DMA pieces; 12 are issued: waves 0-3 two, waves 4-7 one)
+constexpr int NPB = 3;                    // patch buffers: the patch of tile t + 2 is in flight while tile t is computed (round 3)
 constexpr int SOOB = (int)0x80000000;
 
 template <int N> __device__ __forceinline__ void swait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -47,6 +50,10 @@ __device__ __forceinline__ float srow16_sum(float v) {
   return v;
 }
 
+// NOSTORE: the statistics-only launch (train mode, first of the two launches): nothing is converted, staged or stored -- with K = 147 the
+// epilogue's vector instructions outweigh the tile's 56 MFMAs (the kernel is bound by VALU + MFMA issue per SIMD, 16 waves per CU), so
+// the launch that only needs the sums must not pay for the store path.
+template <bool NOSTORE>
 __device__ __forceinline__ void stem_body(const StemArgs& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 patch buffers, then 8 x 2 KiB staging strips
   const int lane = threadIdx.x & 63;
@@ -62,7 +69,7 @@ __device__ __forceinline__ void stem_body(const StemArgs& p) {
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int r = 0; r < 7; ++r) wf[j][r] = *reinterpret_cast<const bf16x8_t*>(p.w + (j * 16 + frow) * 256 + r * 32 + fgrp * 8);
-  float* const vec = reinterpret_cast<float*>(smem + 2 * PBUF + 8 * 2048);          // bias in LDS (read per tile: 16 registers saved)
+  float* const vec = reinterpret_cast<float*>(smem + NPB * PBUF + 8 * 2048);        // bias in LDS (read per tile: 16 registers saved)
   if (threadIdx.x < 64) vec[threadIdx.x] = p.bias ? p.bias[threadIdx.x] : 0.f;
 
   // ---- patch loader: 16 pieces of 1 KiB (64 lanes x 16 B) cover the 703 16-byte chunks of a patch; wave w issues pieces w and w+8
@@ -84,7 +91,8 @@ __device__ __forceinline__ void stem_body(const StemArgs& p) {
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, valid ? (int)(left < 0x7ffff000L ? left : 0x7ffff000L) : 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(smem + buf * PBUF + (wave + i * 8) * 1024), 16, pvo[i], 0, 0, 0);
+      if (i == 0 || wave < 4)          // (12 pieces: wave-uniform, the waits below count per wave)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(smem + buf * PBUF + (wave + i * 8) * 1024), 16, pvo[i], 0, 0, 0);
   };
 
   f32x4_t acc[2][4];
@@ -94,23 +102,28 @@ __device__ __forceinline__ void stem_body(const StemArgs& p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[j][r] = s2[j][r] = 0.f;
 
-  char* const stg = smem + 2 * PBUF + wave * 2048;
+  char* const stg = smem + NPB * PBUF + wave * 2048;
   const int a_off = (lane & 15) * 16 + fgrp * 16;                  // + (2*lr + r) * PROW
   const int srow = lane >> 3, sq = lane & 7;                       // staging read: pixel lane/8 (+8), 16-byte chunk lane%8
 
+  // Round 3: the patch of tile t + 2 is in flight while tile t is computed (three buffers; it was t + 1, and the compiler drained even
+  // that mid-tile: in front of the epilogue's LDS stores hipcc waits vmcnt(0) -- an LDS-DMA may alias -- so every tile waited for a
+  // full HBM latency: 2.2 us per 16 x 16 tile against 0.45 us of MFMAs).  The epilogue's LDS stores are inline asm now.
   long tile = blockIdx.x;
   if (tile < ntiles) issue(tile, 0, true);
+  if (tile + G < ntiles) issue(tile + G, 1, true); else issue(tile, 1, false);
   swait_vm<0>();
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += G) {
-    // my pieces of this tile's patch: everything but the 4 stores of the previous tile's epilogue
-    swait_vm<4>();
+    // my pieces of this tile's patch (issued two tiles ago): everything but the 4 + 4 stores of the two epilogues since and the
+    // pieces of the patch in between (2 for waves 0-3, 1 for waves 4-7)
+    if (wave < 4) swait_vm<(NOSTORE ? 0 : 8) + 2>(); else swait_vm<(NOSTORE ? 0 : 8) + 1>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue(tile + G, buf ^ 1, tile + G < ntiles);
+    issue(tile + 2 * (long)G, buf == 0 ? 2 : buf - 1, tile + 2 * (long)G < ntiles);
     const char* pb = smem + buf * PBUF;
-    buf ^= 1;
+    buf = buf == NPB - 1 ? 0 : buf + 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -146,13 +159,18 @@ __device__ __forceinline__ void stem_body(const StemArgs& p) {
           s2[j][r] = __builtin_fmaf(m, m, s2[j][r]);
           if (p.relu) v[r] = fmaxf(v[r], 0.f);
         }
+        if constexpr (NOSTORE) continue;
         bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        *reinterpret_cast<uint2*>(stg + frow * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8) = *reinterpret_cast<const uint2*>(pk);
+        // (inline asm: see above; the strip is private to the wave and a wave's LDS operations execute in order)
+        asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(uintptr_t)(stg + frow * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8)),
+                     "v"(*reinterpret_cast<const u32x2_t*>(pk))
+                     : "memory");
       }
+      if constexpr (NOSTORE) continue;
       // 16 pixels x 128 B = one contiguous 2 KiB run of the NHWC output: two 16-byte stores per lane.  The descriptor's range
-      // ends with the row's last valid pixel (and is empty for rows past Ho / statistics-only launches): every store is ISSUED.
+      // ends with the row's last valid pixel (and is empty for rows past Ho): every store is ISSUED.
       const long row0 = ((b * p.Ho + ho) * (long)p.Wo + wo0) * 64;
-      const int npx = (ho < p.Ho && !p.no_store) ? (p.Wo - wo0 < 16 ? p.Wo - wo0 : 16) : 0;
+      const int npx = ho < p.Ho ? (p.Wo - wo0 < 16 ? p.Wo - wo0 : 16) : 0;
       const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (npx > 0 ? row0 : 0)), 0, npx * 128, 0x00020000);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -209,7 +227,7 @@ __device__ __forceinline__ void stem_pool_body(const StemPoolArgs& p) {
 #pragma unroll
     for (int r = 0; r < 7; ++r) wf[j][r] = *reinterpret_cast<const bf16x8_t*>(p.w + (j * 16 + frow) * 256 + r * 32 + fgrp * 8);
   // scale / shift live in LDS (behind the conv tile) and are read per tile: 32 registers per lane more for fragment prefetch
-  float* const vec = reinterpret_cast<float*>(smem + 2 * PBUF + 32768);
+  float* const vec = reinterpret_cast<float*>(smem + NPB * PBUF + 32768);
   if (threadIdx.x < 64) { vec[threadIdx.x] = p.scale[threadIdx.x]; vec[64 + threadIdx.x] = p.shift[threadIdx.x]; }
 
   // patch chunk q = piece * 64 + lane: row q / 19, 16-byte column q % 19 (2 pixels)
@@ -234,24 +252,28 @@ __device__ __forceinline__ void stem_pool_body(const StemPoolArgs& p) {
       const int row = r0 + prow_[i], px = c0 + 2 * pcol_[i];
       const bool ok = prow_[i] < 37 && row >= 0 && row < p.Hp && px >= 0 && px + 1 < p.Wp;
       const int vo = ok ? (row * p.Wp + px) * 8 : SOOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(smem + buf * PBUF + (wave + i * 8) * 1024), 16, vo, 0, 0, 0);
+      if (i == 0 || wave < 4)          // (12 pieces: wave-uniform, the waits below count per wave)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(smem + buf * PBUF + (wave + i * 8) * 1024), 16, vo, 0, 0, 0);
     }
   };
 
-  char* const tilebuf = smem + 2 * PBUF;            // [16 conv rows][16 conv cols][64 ch] bf16: 128 B per pixel
+  char* const tilebuf = smem + NPB * PBUF;          // [16 conv rows][16 conv cols][64 ch] bf16: 128 B per pixel
   const int a_off = (lane & 15) * 16 + fgrp * 16;
   long tile = blockIdx.x;
   if (tile < ntiles) issue(tile, 0, true);
+  if (tile + G < ntiles) issue(tile + G, 1, true); else issue(tile, 1, false);
   swait_vm<0>();
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += G) {
-    swait_vm<1>();                                   // my pieces of this tile's patch: everything but the previous tile's (one) store
+    // my pieces of this tile's patch (issued two tiles ago): everything but the two (one-store) epilogues since and the pieces of the
+    // patch in between (2 for waves 0-3, 1 for waves 4-7)
+    if (wave < 4) swait_vm<4>(); else swait_vm<3>();
     __builtin_amdgcn_s_barrier();                    // ... and every wave has finished pooling the previous tile
     asm volatile("" ::: "memory");
-    issue(tile + G, buf ^ 1, tile + G < ntiles);
+    issue(tile + 2 * (long)G, buf == 0 ? 2 : buf - 1, tile + 2 * (long)G < ntiles);
     const char* pb = smem + buf * PBUF;
-    buf ^= 1;
+    buf = buf == NPB - 1 ? 0 : buf + 1;
     f32x4_t acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -283,8 +305,10 @@ __device__ __forceinline__ void stem_pool_body(const StemPoolArgs& p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = ok ? fmaxf(__builtin_fmaf(acc[i][j][r], sc[r], sh[r]), 0.f) : 0.f;
         bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        *reinterpret_cast<uint2*>(tilebuf + (lr * 16 + frow) * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8) =
-            *reinterpret_cast<const uint2*>(pk);
+        // (inline asm: a visible LDS store would make hipcc drain the patches in flight; the lgkmcnt(0) + barrier below cover it)
+        asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(uintptr_t)(tilebuf + (lr * 16 + frow) * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8)),
+                     "v"(*reinterpret_cast<const u32x2_t*>(pk))
+                     : "memory");
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -297,23 +321,19 @@ __device__ __forceinline__ void stem_pool_body(const StemPoolArgs& p) {
     u32x4_t best = {0, 0, 0, 0};
     const bool act = pp < 49;
     if (act) {
-      float m[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) m[c] = 0.f;       // (all candidates are >= 0)
+      // every candidate is a post-ReLU bf16 >= +0 (positions outside the image were written as +0): for such values the order of
+      // the bf16 numbers is the order of their 16-bit patterns, so the 3x3 maximum is nine packed UNSIGNED 16-bit maxima per dword
+      // (v_pk_max_u16: 36 instructions per lane against ~150 for unpack + v_max_f32 + repack)
+      u16x8_t m = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int dh = 0; dh < 3; ++dh)
 #pragma unroll
         for (int dw = 0; dw < 3; ++dw) {
           const int lr = 2 * ph + dh, lc = 2 * pw + dw;           // local conv position (tile origin = conv row 14 th - 1)
-          const u32x4_t t = *reinterpret_cast<const u32x4_t*>(tilebuf + (lr * 16 + lc) * 128 + ((ch ^ (lc & 7)) << 4));
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            m[2 * c] = fmaxf(m[2 * c], __uint_as_float(t[c] << 16));
-            m[2 * c + 1] = fmaxf(m[2 * c + 1], __uint_as_float(t[c] & 0xffff0000u));
-          }
+          const u16x8_t t = *reinterpret_cast<const u16x8_t*>(tilebuf + (lr * 16 + lc) * 128 + ((ch ^ (lc & 7)) << 4));
+          m = __builtin_elementwise_max(m, t);
         }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) best[c] = (__float_as_uint(m[2 * c]) >> 16) | (__float_as_uint(m[2 * c + 1]) & 0xffff0000u);   // (values are exact bf16)
+      best = __builtin_bit_cast(u32x4_t, m);
     }
     // one store per lane and tile (issued by every lane: lanes without a pooled pixel, and pixels past the pooled image, are
     // dropped by the descriptor's range check)
@@ -328,9 +348,10 @@ __device__ __forceinline__ void stem_pool_body(const StemPoolArgs& p) {
 __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs p) { stem_pool_body(p); }
 struct StemPoolTag {};
 
-__global__ __launch_bounds__(512, 2) void stem_conv_kernel(const StemArgs p) { stem_body(p); }
+template <bool NOSTORE>
+__global__ __launch_bounds__(512, 2) void stem_conv_kernel(const StemArgs p) { stem_body<NOSTORE>(p); }
 
-struct StemTag {};
+template <bool NOSTORE> struct StemTag {};
 
 inline bool stem_enabled() {
   static const bool off = [] { const char* e = getenv("SR_NO_STEM_DIRECT"); return e && e[0] == '1'; }();
@@ -366,7 +387,7 @@ extern "C" int sr_stem_bn_relu_maxpool(const void* xp, const void* w, const floa
   if ((long)s.Hp * s.Wp * 8 >= 0x7fffffffL || (long)s.Po * s.Qo * 128 >= 0x7fffffffL) return SR_ERR_UNSUPPORTED;
   const long ntiles = (long)B * s.tiles_h * s.tiles_w;
   if (ntiles > 0x7fffffffL) return SR_ERR_UNSUPPORTED;
-  constexpr int LDS = 2 * PBUF + 32768 + 512;
+  constexpr int LDS = NPB * PBUF + 32768 + 512;
   if (!sr_set_dynamic_lds_tagged<StemPoolTag>(reinterpret_cast<const void*>(&stem_pool_kernel), LDS)) return SR_ERR_LAUNCH;
   hipLaunchKernelGGL(stem_pool_kernel, dim3(stem_grid(ntiles)), dim3(512), LDS, (hipStream_t)stream, s);
   SR_CHECK_LAUNCH();
@@ -385,9 +406,14 @@ int srx_stem_conv(const sr_conv_args* a, void* stream) {
   const long ntiles = (long)s.B * s.tiles_h * s.tiles_w;
   if (ntiles > 0x7fffffffL) return SR_ERR_UNSUPPORTED;
   SR_ROUTE(SR_ROUTE_STEM);
-  constexpr int LDS = 2 * PBUF + 8 * 2048 + 256;
-  if (!sr_set_dynamic_lds_tagged<StemTag>(reinterpret_cast<const void*>(&stem_conv_kernel), LDS)) return SR_ERR_LAUNCH;
-  hipLaunchKernelGGL(stem_conv_kernel, dim3(stem_grid(ntiles)), dim3(512), LDS, (hipStream_t)stream, s);
+  constexpr int LDS = NPB * PBUF + 8 * 2048 + 256;
+  if (s.no_store) {
+    if (!sr_set_dynamic_lds_tagged<StemTag<true>>(reinterpret_cast<const void*>(&stem_conv_kernel<true>), LDS)) return SR_ERR_LAUNCH;
+    hipLaunchKernelGGL(stem_conv_kernel<true>, dim3(stem_grid(ntiles)), dim3(512), LDS, (hipStream_t)stream, s);
+  } else {
+    if (!sr_set_dynamic_lds_tagged<StemTag<false>>(reinterpret_cast<const void*>(&stem_conv_kernel<false>), LDS)) return SR_ERR_LAUNCH;
+    hipLaunchKernelGGL(stem_conv_kernel<false>, dim3(stem_grid(ntiles)), dim3(512), LDS, (hipStream_t)stream, s);
+  }
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
