@@ -439,3 +439,43 @@ def test_direct_128_3x3_normalises_its_input_on_load(ops, B):
     close(lazy.view(-1, Cc), ref.reshape(-1, Cc))
     with pytest.raises(Exception):                                     # eval form (bias + ReLU): not served with an input affine
         ops.conv2d(y1, pack_w(w), Cc, 3, 1, 1, bias=sh, relu=True, in_affine=(sc, sh))
+
+
+def test_cu_share_changes_grids_not_results(ops):
+    """`sr_set_cu_share(2)` (FCGGNN.forward sizes the two backbones' persistent grids for half the compute units each, so that both
+    streams' launches co-reside): the convolution OUTPUT of every kernel family must be bit-identical to the full-grid launch (an
+    output element's K order does not depend on the workgroup that computes it); the BatchNorm partial sums come in a different
+    number of rows (one per workgroup) and must reduce to the same totals up to the fp32 rounding of the per-workgroup running sums."""
+    from situation_recognition_amd import _lib
+    cases = [(256, 256, 3, 14, 700), (1024, 256, 1, 14, 700), (128, 128, 3, 28, 300), (64, 64, 3, 56, 60), (512, 128, 1, 28, 300)]
+    for Cin, Cout, k, H, B in cases:
+        x = F.relu(rnd(B, H, H, Cin, seed=Cin + k)).to(BF)
+        w = rnd(Cout, Cin * k * k, seed=Cout, scale=(Cin * k * k) ** -0.5)
+        y1, s1 = ops.conv2d(x, w, Cout, k, 1, k // 2, want_stats=True)
+        prev = ops.set_cu_share(2)
+        try:
+            y2, s2 = ops.conv2d(x, w, Cout, k, 1, k // 2, want_stats=True)
+        finally:
+            assert ops.set_cu_share(prev) == 2
+        assert torch.equal(y1, y2), (Cin, Cout, k)
+        assert s2.shape[0] < s1.shape[0], (Cin, Cout, k, s1.shape, s2.shape)       # fewer workgroups -> fewer partial rows
+        for c in (0, 1):
+            a, b = s1[:, c].double().sum(0), s2[:, c].double().sum(0)
+            assert float(((a - b).abs() / a.abs().clamp_min(1e-3)).max()) < 2e-5, (Cin, Cout, k, c)
+    # the weight-stationary expansion kernel and the Gram sweep
+    x = F.relu(rnd(700, 14, 14, 256, seed=1)).to(BF)
+    w = rnd(1024, 256, seed=2, scale=256 ** -0.5)
+    idn = rnd(700, 14, 14, 1024, seed=3)
+    esc, bias = 0.5 + torch.rand(1024, device="cuda"), 0.3 * torch.randn(1024, device="cuda")
+    y1 = ops.conv2d(x, w, 1024, 1, 1, 0, bias=bias, escale=esc, res=idn, relu=True)
+    g1 = ops.gram(x.view(-1, 256))
+    prev = ops.set_cu_share(2)
+    try:
+        y2 = ops.conv2d(x, w, 1024, 1, 1, 0, bias=bias, escale=esc, res=idn, relu=True)
+        g2 = ops.gram(x.view(-1, 256))
+    finally:
+        ops.set_cu_share(prev)
+    assert torch.equal(y1, y2)
+    valid = torch.cat([ops.gram_valid_mask(256).reshape(-1), torch.ones(256, dtype=torch.bool)]).cuda()
+    a, b = g1[:, valid].double().sum(0), g2[:, valid].double().sum(0)
+    assert g2.shape[0] < g1.shape[0] and float(((a - b).abs() / a.abs().clamp_min(1.0)).max()) < 2e-5
