@@ -331,6 +331,14 @@ __device__ __forceinline__ void k8_body(const K8Args& p) {
   }
 }
 
+// Tried and removed (round 3): a SPLIT-K form -- the four waves as two pairs, a pair owning 64 output channels and its two waves taking the
+// K-steps of one parity each (28 MFMAs against 7 + 4 fragment reads per step: 0.39 KiB of LDS reads per MFMA instead of 0.64, half the
+// per-step overhead), partial sums exchanged through the dead patch buffer at the end of a tile.  Correct (same tests), and no faster:
+// 1722 us against 1620-1650 us.  Neither is the depth of the weight rings a lever (4 slots: 1650 us; 6: 1620-1650).  Three designs --
+// the generic 256x128 tiles, this kernel, the split-K form -- land within 5 % of each other: at the clock the part holds on this data
+// (1.4-1.55 GHz inside the 3x3 kernels) the tile's 504 MFMAs per wave are ~70 % of the K loop's time, and the
+// rest is the epilogue a single wave per SIMD cannot hide.
+
 template <bool AFF, bool ST, bool IN = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_c128_kernel(const K8Args p) { k8_body<AFF, ST, IN>(p); }
 template <bool AFF, bool ST, bool IN = false> struct K8Tag {};
