@@ -234,8 +234,9 @@ __device__ __forceinline__ void c3_body(const C3Args& p) {
         for (int r = 0; r < 4; ++r) {
           const float a_ = c3row16_sum(s1[j][r >> 1][r & 1]), c_ = c3row16_sum(s2[j][r >> 1][r & 1]);
           if (frow == 0) {
-            __hip_atomic_fetch_add(lstat + (j0 + j) * 16 + fgrp * 4 + r, a_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(lstat + 64 + (j0 + j) * 16 + fgrp * 4 + r, c_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            // (inline asm, like the strip stores below: hipcc guards a visible LDS atomic with a wait for the next tile's patch)
+            const unsigned at = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)(lstat + (j0 + j) * 16 + fgrp * 4 + r);
+            asm volatile("ds_add_f32 %0, %1\n\tds_add_f32 %0, %2 offset:256" ::"v"(at), "v"(a_), "v"(c_) : "memory");
           }
         }
 #pragma unroll
@@ -274,7 +275,11 @@ __device__ __forceinline__ void c3_body(const C3Args& p) {
           }
         }
         bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        *reinterpret_cast<uint2*>(stg + frow * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8) = *reinterpret_cast<const uint2*>(pk);
+        // (inline asm for the same reason as the normalisation's store above: the visible form got `s_waitcnt vmcnt(0)` in front of
+        //  it, i.e. every epilogue waited for the next tile's patch; the strip is wave-private and a wave's LDS operations are in order)
+        asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(stg + frow * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8)),
+                     "v"(*reinterpret_cast<const sr_u32x2*>(pk))
+                     : "memory");
       }
       // 16 pixels x 128 B = one contiguous 2 KiB run of the NHWC output: two 16-byte stores per lane (the descriptor's range is
       // empty for statistics-only launches: every store is ISSUED, so that the wait at the top of the loop can count them)

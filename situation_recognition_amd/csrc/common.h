@@ -83,6 +83,7 @@ inline int sr_num_cus() {
 typedef float sr_f32x2 __attribute__((ext_vector_type(2)));
 typedef float sr_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned sr_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sr_u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 sr_bf16x2 __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr int sr_pair_order(int i) { return (i & 4) | ((i & 1) << 1) | ((i & 2) >> 1); }   // position i of a chunk holds channel ...
 __device__ __forceinline__ sr_u32x4 sr_affine_relu_chunk(sr_u32x4 v, sr_f32x4 s0, sr_f32x4 s1, sr_f32x4 h0, sr_f32x4 h1) {

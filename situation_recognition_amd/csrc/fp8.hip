@@ -24,6 +24,7 @@ namespace {
 
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 struct F8Args {
   const unsigned char* x;      // [B, H, W, Cin] e4m3
@@ -199,7 +200,11 @@ __device__ __forceinline__ void conv3x3_fp8_body(const F8Args& p) {
           acc[j][i][r] = 0.f;
         }
         bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        *reinterpret_cast<uint2*>(stg + frow * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8) = *reinterpret_cast<const uint2*>(pk);
+        // (inline asm: a visible LDS store makes hipcc put s_waitcnt vmcnt(0) in front of it while LDS-DMA is in flight, which drains
+        //  the two steps already fetched for the next tile; the strip is private to the wave and a wave's LDS operations execute in order)
+        asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(uintptr_t)(stg + frow * 128 + (((j * 2 + (fgrp >> 1)) ^ (frow & 7)) << 4) + (fgrp & 1) * 8)),
+                     "v"(*reinterpret_cast<const u32x2_t*>(pk))
+                     : "memory");
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {

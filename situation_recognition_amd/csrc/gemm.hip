@@ -469,7 +469,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(c
 //   without them -- the registers go to a deeper residual prefetch instead.
 template <typename T, typename TO, bool CONV, int CFG, int EPIX>
 __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
-  constexpr int EPI = EPIX == 1 ? 0 : EPIX;
+  // EPIX: 0 linear, 1 linear + BatchNorm statistics, 6 linear + row residual (16-bit outputs), else the SR_ACT_* code of a fused epilogue
+  constexpr int EPI = (EPIX == 1 || EPIX == 6) ? 0 : EPIX;
   constexpr bool ST = EPIX == 1;
   constexpr int WAVES_N = CFG == 8 ? 2 : CFG, FN = CFG == 8 ? 8 : 4;   // FN: 16-column fragments per wave along N
   constexpr int WAVES_M = CFG == 1 ? 4 : 2, FM = 16 / WAVES_M;          // FM: 16-row fragments per wave along M
@@ -778,8 +779,13 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     if (!p.no_store) {
     // 16-bit outputs with a residual: the residual is NOT fetched in fragment layout (4 scattered columns per lane) but as
     // whole 16-byte row chunks, coalesced, one strip ahead, and added (+ReLU) after the LDS transpose, on the output rows.
-    constexpr bool ROWRES = STAGED && EPI == 0 && !ST;   // (statistics kernels: a residual takes the fragment-layout path; their registers hold the running sums)
-    const bool rowres = ROWRES && p.res != nullptr;
+    // A kernel of its own (EPIX 6; the host picks it whenever p.res is set and the output is 16-bit), not a run-time flag of the
+    // linear kernel: with `rowres` tested at the fetch and again at the use, hipcc's wait-count pass (path-insensitive) took the
+    // residual loads for possibly still pending on the path WITHOUT a residual and put `s_waitcnt vmcnt(0)` in front of the K
+    // loop's fragment reads, which reuse those registers -- executed in every step, with or without a residual: the LDS-DMA ring
+    // never held more than the step being waited for.  (Statistics kernels: a residual takes the fragment-layout path.)
+    constexpr bool ROWRES = STAGED && EPIX == 6;
+    constexpr bool rowres = ROWRES;
     // The residual is requested RD strips ahead (RD*NH 16-byte loads per lane in flight, in the registers the K loop's
     // fragments no longer need): one strip ahead left every strip waiting a full HBM latency for its residual; all FM
     // strips at once spills.
@@ -893,6 +899,16 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
 #ifdef SR_STAMPS
     if (estamp) { SR_STAMP(te1); te_store += te1 - te0; }
 #endif
+    // Every register a global load of this epilogue targeted is USED here, on all paths: a per-column vector loaded under one
+    // condition and consumed under another (a `no_store` launch never reads its multipliers) stays "possibly pending" for hipcc's
+    // path-insensitive wait-count pass, which then guards the K loop's fragment reads (same registers) with `s_waitcnt vmcnt(0)`
+    // in every step.  Where the values were consumed this costs nothing; elsewhere it is one wait per tile instead of one per step.
+    if constexpr (!ST) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(ev[j][r]), "v"(bv[j][r]));
+    }
   };
 
   // (A start offset of half a tile period between the two workgroups of a CU -- so that one drains its stores while the
@@ -1256,20 +1272,28 @@ int launch_v3(const KArgs& k_in, hipStream_t st) {
     if (k.stats) {
       if (!sr_set_dynamic_lds<&conv_igemm_v3_kernel<T, TO, WN, 1>>((int)lds)) return SR_ERR_LAUNCH;
       hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN, 1>), dim3(grid), dim3(NTHR), lds, st, k);
+    } else if (sizeof(TO) == 2 && k.res) {
+      constexpr int E = sizeof(TO) == 2 ? 6 : 0;
+      if (!sr_set_dynamic_lds<&conv_igemm_v3_kernel<T, TO, WN, E>>((int)lds)) return SR_ERR_LAUNCH;
+      hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN, E>), dim3(grid), dim3(NTHR), lds, st, k);
     } else {
       if (!sr_set_dynamic_lds<&conv_igemm_v3_kernel<T, TO, WN, 0>>((int)lds)) return SR_ERR_LAUNCH;
       hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN, 0>), dim3(grid), dim3(NTHR), lds, st, k);
     }
   } else if constexpr (WN <= 2) {
     // narrow tiles: linear epilogue only (caller guarantees)
-    rc = k.stats ? launch_v3e<T, TO, WN, 1>(k, grid, lds, st) : launch_v3e<T, TO, WN, 0>(k, grid, lds, st);
+    rc = k.stats ? launch_v3e<T, TO, WN, 1>(k, grid, lds, st)
+                 : (sizeof(TO) == 2 && k.res ? launch_v3e<T, TO, WN, (sizeof(TO) == 2 ? 6 : 0)>(k, grid, lds, st) : launch_v3e<T, TO, WN, 0>(k, grid, lds, st));
   } else {
     switch (k.act) {
       case SR_ACT_SIGMOID: rc = launch_v3e<T, TO, WN, SR_ACT_SIGMOID>(k, grid, lds, st); break;
       case SR_ACT_TANH: rc = launch_v3e<T, TO, WN, SR_ACT_TANH>(k, grid, lds, st); break;
       case SR_ACT_SIGMOID_MUL: rc = launch_v3e<T, TO, WN, SR_ACT_SIGMOID_MUL>(k, grid, lds, st); break;
       case SR_ACT_TANH_BLEND: rc = launch_v3e<T, TO, WN, SR_ACT_TANH_BLEND>(k, grid, lds, st); break;
-      default: rc = k.stats ? launch_v3e<T, TO, WN, 1>(k, grid, lds, st) : launch_v3e<T, TO, WN, 0>(k, grid, lds, st); break;
+      default:
+        rc = k.stats ? launch_v3e<T, TO, WN, 1>(k, grid, lds, st)
+                     : (sizeof(TO) == 2 && k.res ? launch_v3e<T, TO, WN, (sizeof(TO) == 2 ? 6 : 0)>(k, grid, lds, st) : launch_v3e<T, TO, WN, 0>(k, grid, lds, st));
+        break;
     }
   }
   if (rc != SR_OK) return rc;
