@@ -325,6 +325,11 @@ def test_narrow_tile_kernels_at_multi_tile_production_shapes(ops, Cin, Cout, k, 
     bias = 0.3 * torch.randn(Cout, device="cuda")
     y2 = ops.conv2d(x, pack_w(w), Cout, k, 1, pad, bias=bias, relu=True)
     close(y2.view(M, Cout), F.relu(ref + bias))
+    # eval form of a block's last conv: bias + row-layout residual + ReLU (the residual epilogue is a kernel of its own, EPIX 6)
+    idn = rnd(B, H, H, Cout, seed=Cout + 7).to(BF)
+    y4 = ops.conv2d(x, pack_w(w), Cout, k, 1, pad, bias=bias, res=idn, relu=True)
+    close(y4.view(M, Cout), F.relu(ref + bias + idn.float().view(M, Cout)))
+    del y4, idn
     # through the BatchNorm it feeds
     gamma, beta = 0.5 + torch.rand(Cout, device="cuda"), 0.2 * torch.randn(Cout, device="cuda")
     scale, shift = ops.bn_finalize(stats, M, gamma, beta, None, None, 0.1, 1e-5)
