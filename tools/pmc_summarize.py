@@ -29,6 +29,21 @@ def counter_sum(path, name):
     return s, n
 
 
+def by_kernel(path, name):
+    """per-kernel totals of one counter (all kernels of the run) -> pmc_<counter>_<tag>_by_kernel.csv"""
+    per = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == name:
+            a = per[r["Kernel_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    with open(os.path.join(out, "pmc_%s_%s_by_kernel.csv" % (name.lower(), tag)), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Dispatches", name + "_KiB_sum", "KiB_per_dispatch"])
+        for k, (n, v) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, n, "%.1f" % v, "%.1f" % (v / n)])
+
+
+by_kernel(fetch, "FETCH_SIZE")
+by_kernel(write, "WRITE_SIZE")
 fs, fn = counter_sum(fetch, "FETCH_SIZE")
 ws, wn = counter_sum(write, "WRITE_SIZE")
 res = {
