@@ -469,9 +469,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_v2_kernel(c
 //   without them -- the registers go to a deeper residual prefetch instead.
 template <typename T, typename TO, bool CONV, int CFG, int EPIX>
 __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
-  // EPIX: 0 linear, 1 linear + BatchNorm statistics, 6 linear + row residual (16-bit outputs), else the SR_ACT_* code of a fused epilogue
-  constexpr int EPI = (EPIX == 1 || EPIX == 6) ? 0 : EPIX;
-  constexpr bool ST = EPIX == 1;
+  // EPIX: 0 linear, 1 linear + BatchNorm statistics, 6 linear + row residual (16-bit outputs), 7 RAW output + statistics (no bias,
+  // multiplier, residual or activation: every train-mode convolution of the backbone), else the SR_ACT_* code of a fused epilogue
+  constexpr int EPI = (EPIX == 1 || EPIX == 6 || EPIX == 7) ? 0 : EPIX;
+  constexpr bool ST = EPIX == 1 || EPIX == 7;
+  constexpr bool PLAIN = EPIX == 7;
   constexpr int WAVES_N = CFG == 8 ? 2 : CFG, FN = CFG == 8 ? 8 : 4;   // FN: 16-column fragments per wave along N
   constexpr int WAVES_M = CFG == 1 ? 4 : 2, FM = 16 / WAVES_M;          // FM: 16-row fragments per wave along M
   constexpr int BM = 256, BN = 16 * FN * WAVES_N, NW = WAVES_M * WAVES_N;
@@ -911,6 +913,88 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
     }
   };
 
+  // ---------------- EPIX 7: raw output + statistics, one pass over the accumulators ----------------
+  // The general epilogue above walks the accumulators twice (statistics column-major, then the strips) and its strip loop is
+  // cut into basic blocks by the run-time options (fragment-layout residual, ReLU, edge masks), so every strip's LDS round trip
+  // -- 4 fragment writes, 2 row reads, the wait for them -- lies bare: in-kernel stamps gave 2.0 K cycles for the statistics and
+  // 6.8 K for the strips of a 256x256 tile (11.6 K with the rest; a K = 1024 tile's loop is 53 K).  Without options the pass is
+  // straight-line: fragment (i, j) is read from the accumulators ONCE, added to the lane's running sums (rows past M and columns past
+  // N are exact zeros -- their operand rows were zero-filled by the loader and there is no bias -- so no masks), converted and
+  // written to strip i & 1; the row reads of strip i are issued BEFORE strip i + 1 is converted and its stores after, so the LDS
+  // latency hides under the next strip's arithmetic (256x256 tiles: two strips per wave fill the 32 KiB slot; the narrow tiles'
+  // staging area holds one strip per wave: same order, no overlap).
+  auto epilogue_plain = [&](int tile) {
+   if constexpr (PLAIN) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    constexpr int NSTG = CFG == 4 ? 2 : 1;
+    static_assert(!(CFG == 4) || NW * NSTG * 16 * CPR * 16 <= SLOT, "two strips per wave fit the ring slot");
+    const int tm = tile / gn, tn = tile - tm * gn;
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+    const int el = fresh_lane();
+    const int frow = el & 15, fgrp = el >> 4;
+    char* const stg0 = smem + stg_off + wave * (NSTG * 16 * CPR * 16);
+    const bool store = !p.no_store;
+    auto put = [&](int i) {
+      char* const stg = stg0 + (i % NSTG) * (16 * CPR * 16);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const f32x2_t v01 = {acc[j][i][0], acc[j][i][1]}, v23 = {acc[j][i][2], acc[j][i][3]};
+        f32x2_t a01 = {rs1[j][0], rs1[j][1]}, a23 = {rs1[j][2], rs1[j][3]}, q01 = {rs2[j][0], rs2[j][1]}, q23 = {rs2[j][2], rs2[j][3]};
+        a01 += v01; a23 += v23;
+        q01 = __builtin_elementwise_fma(v01, v01, q01);
+        q23 = __builtin_elementwise_fma(v23, v23, q23);
+        rs1[j][0] = a01[0]; rs1[j][1] = a01[1]; rs1[j][2] = a23[0]; rs1[j][3] = a23[1];
+        rs2[j][0] = q01[0]; rs2[j][1] = q01[1]; rs2[j][2] = q23[0]; rs2[j][3] = q23[1];
+        if (store) {
+          const float v[4] = {v01[0], v01[1], v23[0], v23[1]};
+          if constexpr (STAGED) {
+            // (inline asm: in this straight-line form hipcc puts `s_waitcnt vmcnt(0)` in front of a visible LDS store -- the
+            //  next tile's LDS-DMA may alias -- and drains the ring; the strip is wave-private and a wave's LDS operations are in order)
+            bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(uintptr_t)(stg + frow * (CPR * 16) + (((j * 2 + (fgrp >> 1)) ^ (frow & (CPR - 1))) << 4) + (fgrp & 1) * 8)),
+                         "v"(*reinterpret_cast<const sr_u32x2*>(pk))
+                         : "memory");
+          } else {
+            const long m = m0 + wm * FM * 16 + i * 16 + frow;
+            const int n = n0 + wn * FN * 16 + j * 16 + fgrp * 4;
+            store4<TO>((m < p.M && n < Nv) ? (TO*)p.C + m * p.ldc + n : reinterpret_cast<TO*>((char*)p.trash_page + el * 16), v);
+          }
+        }
+      }
+    };
+    put(0);
+    if (STAGED && store) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const char* const stg = stg0 + (i % NSTG) * (16 * CPR * 16);
+        sr_u32x4 val[NH];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const int r16 = h * RPI + el / CPR;
+          val[h] = *reinterpret_cast<const sr_u32x4*>(stg + r16 * (CPR * 16) + ((((el % CPR)) ^ (r16 & (CPR - 1))) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < FM) put(i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const int r16 = h * RPI + el / CPR, c8 = (el % CPR) * 8;
+          const long mm = m0 + wm * FM * 16 + i * 16 + r16;
+          const int nn = n0 + wn * FN * 16 + c8;
+          const bool okk = (mm < p.M) && (nn + 8 <= Nv);
+          *reinterpret_cast<sr_u32x4*>(okk ? (char*)((TO*)p.C + mm * p.ldc + nn) : (char*)p.trash_page + el * 16) = val[h];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 1; i < FM; ++i) put(i);
+    }
+    if (++st_cnt == SR_STATS_FLUSH || tile + G >= ntiles) stats_flush(false);
+   }
+  };
+
   // (A start offset of half a tile period between the two workgroups of a CU -- so that one drains its stores while the
   //  other multiplies -- was worth a few percent with the first K loops and costs 2-4 % with this one: removed.)
   // ---------------- K loop ----------------
@@ -1082,7 +1166,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         if (c_left == 0) {
           if (wm == 0) __builtin_amdgcn_s_barrier();     // re-align
           stg_off = (slot == 0 ? NSLOT - 1 : slot - 1) * SLOT;   // the slot of the step just consumed: free until the next DMA
-          epilogue(c_tile);
+          if constexpr (PLAIN) epilogue_plain(c_tile); else epilogue(c_tile);
           since_epi = p.no_store ? 0 : D - 1;
           c_left = nkt;
           c_tile += G;
@@ -1151,7 +1235,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         c_left -= n;
         if (seg_left == 0) advance_tail();
         if (c_left == 0) {
-          epilogue(c_tile);
+          if constexpr (PLAIN) epilogue_plain(c_tile); else epilogue(c_tile);
           since_epi = p.no_store ? 0 : D;
           c_left = nkt;
           c_tile += G;
@@ -1268,8 +1352,14 @@ int launch_v3(const KArgs& k_in, hipStream_t st) {
   k.stats_nflush = (int)pl.nflush;
   const unsigned grid = (unsigned)pl.grid;
   int rc = SR_OK;
+  // raw output + statistics and nothing else (every train-mode convolution of the backbone): the one-pass epilogue, EPIX 7
+  const bool plain = sizeof(T) == 2 && sizeof(TO) == 2 && k.stats && !k.bias && !k.bias2 && !k.res && !k.escale && k.act == SR_ACT_NONE;
   if (k.cv.on) {
-    if (k.stats) {
+    if (plain) {
+      constexpr int E = (sizeof(T) == 2 && sizeof(TO) == 2) ? 7 : 1;
+      if (!sr_set_dynamic_lds<&conv_igemm_v3_kernel<T, TO, WN, E>>((int)lds)) return SR_ERR_LAUNCH;
+      hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN, E>), dim3(grid), dim3(NTHR), lds, st, k);
+    } else if (k.stats) {
       if (!sr_set_dynamic_lds<&conv_igemm_v3_kernel<T, TO, WN, 1>>((int)lds)) return SR_ERR_LAUNCH;
       hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN, 1>), dim3(grid), dim3(NTHR), lds, st, k);
     } else if (sizeof(TO) == 2 && k.res) {
