@@ -1105,7 +1105,10 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
       // Runs of steps are an inner loop that never redefines the loader's registers: a segment change (next tap /
       // operand pair / tile: setup_ptrs) happens BETWEEN runs, as does the epilogue.  With that slow path inside the step,
       // hipcc copied ~25 loop-carried registers per step; two copies of the step body (steady / generic) made it spill.
-      auto pp_step = [&](bool steady, int s) {
+      // FIRST (a tile's first step; PLAIN kernels): the MFMAs take a zero C operand instead of accumulators that 128
+      // `v_accvgpr_write` per wave cleared after the epilogue
+      auto pp_step = [&](auto FIRST_, bool steady, int s) {
+        constexpr bool FIRST = decltype(FIRST_)::value;
 #ifdef SR_STAMPS
         if (stamp) SR_STAMP(t0);
 #endif
@@ -1136,6 +1139,10 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
         for (int k = 0; k < FN / 2; ++k) {
 #pragma unroll
           for (int i = 0; i < FM; ++i) {
+            if constexpr (FIRST) {
+              acc[2 * k][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+              acc[2 * k + 1][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
             mma<T>(b[2 * k], a[i], acc[2 * k][i]);
             mma<T>(b[2 * k + 1], a[i], acc[2 * k + 1][i]);
           }
@@ -1151,6 +1158,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
 #endif
       };
       int s = 0;
+      const bool zfirst = PLAIN && !(p.debug & 64);    // (SR_GEMM_DEBUG bit 64: clear the accumulators instead -- A/B measurements)
       while (s < total) {
         const bool steady = since_epi == 0 && issued - s == D && issued < total;   // (n >= 1 below: all three terms are)
         int n = 1;
@@ -1159,7 +1167,12 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
           n = c_left < n ? c_left : n;
           n = seg_left < n ? seg_left : n;
         }
-        for (int i = 0; i < n; ++i) pp_step(steady, s + i);
+        if (zfirst && c_left == nkt && s > 0) {        // a tile's first step behind an epilogue: one step in the general (counted-wait) form
+          n = 1;
+          pp_step(std::true_type{}, false, s);
+        } else {
+          for (int i = 0; i < n; ++i) pp_step(std::false_type{}, steady, s + i);
+        }
         s += n;
         c_left -= n;
         if (seg_left == 0) advance_tail();
@@ -1170,7 +1183,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
           since_epi = p.no_store ? 0 : D - 1;
           c_left = nkt;
           c_tile += G;
-          clear_acc();
+          if (!zfirst) clear_acc();
           if (s < total) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // every wave is done with its staging strip: the slot may be refilled
