@@ -67,8 +67,9 @@ B14 = 1024                                            # 1024 x 14 x 14 = 200 704
 
 
 def test_conv3x3_256_256_statistics_kernel(ops):
-    """layer3's 3x3 (35 launches per pass, 14 % of the step): `<bf16,bf16,4,1>` -- raw bf16 output + running BatchNorm
-    partial sums over 3-4 tiles per workgroup; padding taps through out-of-range buffer loads."""
+    """layer3's 3x3 (35 launches per pass, 14 % of the step): `<bf16,bf16,4,7>` (one-pass raw + statistics epilogue) -- raw bf16
+    output + running BatchNorm partial sums over 3-4 tiles per workgroup; padding taps through out-of-range buffer loads.  Then the
+    GENERAL statistics kernel `<bf16,bf16,4,1>` (statistics of conv + bias, masked edge path) on the same operands."""
     Cc = 256
     M = B14 * 196
     assert cfg(ops, M, Cc) == 4
@@ -90,6 +91,18 @@ def test_conv3x3_256_256_statistics_kernel(ops):
     want = F.relu(F.batch_norm(ref.t().reshape(1, Cc, M), None, None, gamma, beta, training=True, eps=1e-5)).view(Cc, M).t()
     out = ops.bn_apply(y, scale, shift, relu=True)
     close(out.view(M, Cc), want, k=2.0)
+    del out, want
+    # a bias moves the launch to the general statistics kernel: output and sums are those of conv + bias; and a statistics-only
+    # launch of either kernel returns exactly the sums of its storing launch
+    bias = 0.3 * torch.randn(Cc, device="cuda")
+    yb, sb = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, bias=bias, want_stats=True)
+    refb = ref + bias
+    close(yb.view(M, Cc), refb)
+    b1, b2 = sb[:, 0].double().sum(0), sb[:, 1].double().sum(0)
+    assert float((b1 - refb.double().sum(0)).abs().max()) < 1e-4 * float(refb.abs().sum(0).max())
+    assert float(((b2 - (refb.double() ** 2).sum(0)).abs() / (refb.double() ** 2).sum(0)).max()) < 1e-4
+    assert torch.equal(ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, stats_only=True), stats)
+    assert torch.equal(ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, bias=bias, stats_only=True), sb)
 
 
 def test_conv1x1_256_1024_scale_residual_relu(ops):
