@@ -44,7 +44,7 @@ extern "C" {
 
 /* Bumped on every incompatible change of a signature or struct below (2: sr_conv_args grew in_scale / in_shift, sr_bn_finalize*
  * gained the twin buffers; 3: sr_conv_route, sr_comm_* / sr_allreduce_sum).  A binding must refuse a library whose version differs. */
-#define SR_ABI_VERSION 3
+#define SR_ABI_VERSION 4
 int sr_abi_version(void);
 
 /* Launches that follow (from any thread) size their persistent grids for 1/share of the device's compute units (share 1..8;
@@ -242,7 +242,9 @@ int sr_node_init_fwd(const void* feat, const float* role_emb, const float* verb_
  *   order    int32 [B]     image indices sorted (stably) by verb id
  *   seg      int32 [V+1]   order[seg[v] .. seg[v+1]) are the images of verb v
  *   inv_ptr  int32 [NR+1], inv_slot int32 [nnz]: inv_slot[inv_ptr[q] .. inv_ptr[q+1]) = the slots v*R+r with role_table[v][r] == q
- *   scratch  fp32 [V*R*D]  per-(verb, slot) partial sums
+ *   scratch  fp32 [(V + 2*ceil(B/32)) * R * D]  per-(verb, slot) sums, then two partial-sum slabs per 32-image chunk of `order`
+ *            (a verb's images are summed chunk by chunk, so that a batch dominated by one verb is not walked by one wave;
+ *            ABI 4: the first form took V*R*D floats)
  * feat gets no gradient (frozen backbone, model.py:17-18). */
 int sr_node_init_bwd(const void* dnode, const void* feat, const float* role_emb, const float* verb_emb,
                      const int32_t* order, const int32_t* seg, const int32_t* role_table, const int32_t* inv_ptr,

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SR_LIB_PATH") or os.path.join(_HERE, "libsrhip.so")   # SR_LIB_PATH: diagnostic builds only
 
-ABI_VERSION = 3                  # include/srhip.h: SR_ABI_VERSION
+ABI_VERSION = 4                  # include/srhip.h: SR_ABI_VERSION
 SR_F32, SR_BF16 = 0, 1
 ROUTE_WS, ROUTE_C3D, ROUTE_STEM, ROUTE_C3D128 = 16, 18, 19, 20     # sr_conv_route codes
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SIGMOID_MUL, ACT_TANH_BLEND = range(6)

@@ -50,62 +50,128 @@ __global__ void node_init_fwd_kernel(const T* __restrict__ feat, const float* __
 // Backward of node init, deterministic (no atomics).  y = relu(f*ro*ve):  d ro = g*[y>0]*f*ve ; d ve = sum_r g*[y>0]*f*ro.
 // Within one verb v the factors ve (and ro of slot r) are constant, so with S[v,r,:] = sum_{b: verb_b = v} g_{b,r}*[y>0]*f_b
 //     d_verb[v] = sum_r ro[rid(v,r)] * S[v,r]          d_role[rid] = sum_{(v,r): rid(v,r) = rid} ve[v] * S[v,r].
-// Phase 1: one wave per (verb, 64 x 16-byte column strip) walks the verb's images in the (stable) sorted order the host hands
-// over and writes S and d_verb; phase 2: one wave per (role, strip) walks the role's (verb, slot) list -- a static inverted
-// index of the encoder's role table.  Every sum has a fixed order: gradients are bit-reproducible (the atomic version was
-// not: ~190 adders per d_role row at batch 6144).
+// Phase 1a: the batch, in the (stable) verb-sorted order the host hands over, is cut into CHUNKS of kChunk positions; one wave per
+// (chunk, 64 x 16-byte column strip) walks its positions and sums each verb's run.  A verb whose images all lie inside the chunk is
+// finished there (S and d_verb written); a run that reaches the chunk's start or end leaves a partial: PH[chunk] (the run that
+// begins at the chunk's first position) or PT[chunk] (the run that begins inside and continues past its end).  Phase 1b: one wave
+// per (verb, strip) adds the partials of a verb that spans chunks, in chunk order, and writes zeros for absent verbs.  Phase 2: one
+// wave per (role, strip) walks the role's (verb, slot) list -- a static inverted index of the encoder's role table.  Every sum has
+// a fixed order: gradients are bit-reproducible (the atomic version was not: ~190 adders per d_role row at batch 6144).
+// (Round 3: the first form gave one wave a WHOLE verb.  With most images on one verb -- argmax of an untrained verb head, or any
+//  skewed batch -- that wave walked thousands of images alone: 2.3 ms at batch 6144 for 180 MB of traffic.)
+constexpr int kChunk = 32;
+
+// largest v with seg[v] <= pos (< seg[v+1]): the verb of sorted position pos (seg is non-decreasing, seg[0] = 0, seg[V] = B > pos)
+__device__ __forceinline__ int verb_of_position(const int32_t* __restrict__ seg, int V, int pos) {
+  int lo = 0, hi = V;                                  // invariant: seg[lo] <= pos < seg[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg[mid] <= pos) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 template <typename T>
-__global__ __launch_bounds__(64) void node_init_bwd1_kernel(const T* __restrict__ dnode, const T* __restrict__ feat,
-                                                            const float* __restrict__ role_emb, const float* __restrict__ verb_emb,
-                                                            const int32_t* __restrict__ order, const int32_t* __restrict__ seg,
-                                                            const int32_t* __restrict__ role_table, float* __restrict__ S,
-                                                            float* __restrict__ d_verb, int R, int D, int NR,
-                                                            const int32_t* __restrict__ offs) {
+__global__ __launch_bounds__(64) void node_init_bwd1a_kernel(const T* __restrict__ dnode, const T* __restrict__ feat,
+                                                             const float* __restrict__ role_emb, const float* __restrict__ verb_emb,
+                                                             const int32_t* __restrict__ order, const int32_t* __restrict__ seg,
+                                                             const int32_t* __restrict__ role_table, float* __restrict__ S,
+                                                             float* __restrict__ PH, float* __restrict__ PT,
+                                                             float* __restrict__ d_verb, int B, int R, int D, int V, int NR,
+                                                             const int32_t* __restrict__ offs) {
   constexpr int N = Vec16<T>::N;
-  const int v = blockIdx.x;
+  const int chunk = blockIdx.x, c0 = chunk * kChunk, c1 = min(B, c0 + kChunk);
   const int d = (blockIdx.y * 64 + threadIdx.x) * N;
   if (d >= D) return;
-  float ve[N], ro[kMaxR][N], acc[kMaxR][N];
-  int rid[kMaxR];
+  // the chunk's image indices and first node rows, one per lane (read by lane index below: no dependent loads in the walk)
+  const int pos = c0 + (int)(threadIdx.x & (kChunk - 1));
+  const int my_b = pos < c1 ? order[pos] : 0;
+  const int my_o = offs ? offs[my_b] : my_b * R;
+  int v = verb_of_position(seg, V, c0);
+  int i = c0;
+  while (i < c1) {
+    const int s0 = seg[v], s1 = seg[v + 1];
+    const int e = s1 < c1 ? s1 : c1;
+    float ve[N], ro[kMaxR][N], acc[kMaxR][N];
+    int rid[kMaxR];
 #pragma unroll
-  for (int k = 0; k < N; ++k) ve[k] = verb_emb[(long)v * D + d + k];
-#pragma unroll
-  for (int r = 0; r < kMaxR; ++r) {
-    rid[r] = r < R ? role_table[v * R + r] : NR;
-#pragma unroll
-    for (int k = 0; k < N; ++k) { ro[r][k] = rid[r] != NR ? role_emb[(long)rid[r] * D + d + k] : 0.f; acc[r][k] = 0.f; }
-  }
-  for (int i = seg[v]; i < seg[v + 1]; ++i) {
-    const long b = order[i];
-    Vec16<T> f = ld16<T>(feat + b * D + d);
+    for (int k = 0; k < N; ++k) ve[k] = verb_emb[(long)v * D + d + k];
 #pragma unroll
     for (int r = 0; r < kMaxR; ++r) {
-      if (r < R && rid[r] != NR) {
-        Vec16<T> g = ld16<T>(dnode + ((offs ? (long)offs[b] : b * R) + r) * D + d);     // (packed: a real role r is always < the image's count)
+      rid[r] = r < R ? role_table[v * R + r] : NR;
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-          const float fx = f.get(k);
-          const float pre = fx * ro[r][k] * ve[k];
-          acc[r][k] += pre > 0.f ? g.get(k) * fx : 0.f;
+      for (int k = 0; k < N; ++k) { ro[r][k] = rid[r] != NR ? role_emb[(long)rid[r] * D + d + k] : 0.f; acc[r][k] = 0.f; }
+    }
+    const int first = i;
+    for (; i < e; ++i) {
+      const long b = __builtin_amdgcn_readlane(my_b, i - c0);
+      const long row0 = __builtin_amdgcn_readlane(my_o, i - c0);
+      Vec16<T> f = ld16<T>(feat + b * D + d);
+#pragma unroll
+      for (int r = 0; r < kMaxR; ++r) {
+        if (r < R && rid[r] != NR) {
+          Vec16<T> g = ld16<T>(dnode + (row0 + r) * D + d);                  // (packed: a real role r is always < the image's count)
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const float fx = f.get(k);
+            const float pre = fx * ro[r][k] * ve[k];
+            acc[r][k] += pre > 0.f ? g.get(k) * fx : 0.f;
+          }
         }
       }
     }
-  }
-  float dve[N];
+    const bool whole = s0 >= c0 && s1 <= c1;
+    float* const dst = whole ? S + (long)v * R * D : (first == c0 ? PH : PT) + (long)chunk * R * D;
+    float dve[N];
 #pragma unroll
-  for (int k = 0; k < N; ++k) dve[k] = 0.f;
+    for (int k = 0; k < N; ++k) dve[k] = 0.f;
 #pragma unroll
-  for (int r = 0; r < kMaxR; ++r) {
-    if (r < R) {
+    for (int r = 0; r < kMaxR; ++r) {
+      if (r < R) {
 #pragma unroll
-      for (int k = 0; k < N; ++k) {
-        dve[k] += acc[r][k] * ro[r][k];
-        S[((long)v * R + r) * D + d + k] = acc[r][k];
+        for (int k = 0; k < N; ++k) {
+          dve[k] += acc[r][k] * ro[r][k];
+          dst[(long)r * D + d + k] = acc[r][k];
+        }
       }
     }
-  }
+    if (whole) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) d_verb[(long)v * D + d + k] = dve[k];
+      for (int k = 0; k < N; ++k) d_verb[(long)v * D + d + k] = dve[k];
+    }
+    do { ++v; } while (v < V && seg[v + 1] <= i);      // the next verb that has images at or behind position i
+  }
+}
+
+// Phase 1b: verbs absent from the batch (zeros) and verbs whose run crosses a chunk boundary (partials added in chunk order).
+__global__ __launch_bounds__(64) void node_init_bwd1b_kernel(const float* __restrict__ role_emb, const int32_t* __restrict__ seg,
+                                                             const int32_t* __restrict__ role_table, float* __restrict__ S,
+                                                             const float* __restrict__ PH, const float* __restrict__ PT,
+                                                             float* __restrict__ d_verb, int R, int D, int NR) {
+  const int v = blockIdx.x;
+  const int d = (blockIdx.y * 64 + threadIdx.x) * 4;
+  if (d >= D) return;
+  const int s = seg[v], e = seg[v + 1];
+  const int jf = s / kChunk, jl = e > s ? (e - 1) / kChunk : jf;
+  if (e > s && jf == jl) return;                         // finished by phase 1a
+  float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < R; ++r) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e > s) {
+      a = *reinterpret_cast<const float4*>((s % kChunk == 0 ? PH : PT) + ((long)jf * R + r) * D + d);
+      for (int j = jf + 1; j <= jl; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(PH + ((long)j * R + r) * D + d);
+        a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+      }
+      const int rid = role_table[v * R + r];
+      if (rid != NR) {
+        const float4 w = *reinterpret_cast<const float4*>(role_emb + (long)rid * D + d);
+        dv.x += a.x * w.x; dv.y += a.y * w.y; dv.z += a.z * w.z; dv.w += a.w * w.w;
+      }
+    }
+    *reinterpret_cast<float4*>(S + ((long)v * R + r) * D + d) = a;
+  }
+  *reinterpret_cast<float4*>(d_verb + (long)v * D + d) = dv;
 }
 
 __global__ __launch_bounds__(64) void node_init_bwd2_kernel(const float* __restrict__ S, const float* __restrict__ verb_emb,
@@ -268,9 +334,16 @@ extern "C" int sr_node_init_bwd(const void* dnode, const void* feat, const float
   const int n = dtype == SR_F32 ? 4 : 8;
   if (D % n || D % 4) return SR_ERR_ARG;
   const unsigned gy1 = (unsigned)((D / n + 63) / 64), gy2 = (unsigned)((D / 4 + 63) / 64);
-  DT_SWITCH(dtype, hipLaunchKernelGGL(node_init_bwd1_kernel<T>, dim3((unsigned)V, gy1), dim3(64), 0, (hipStream_t)stream,
-                                      (const T*)dnode, (const T*)feat, role_emb, verb_emb, order, seg, role_table, scratch,
-                                      d_verb_emb, R, D, NR, offs));
+  const long nchunk = ((long)B + kChunk - 1) / kChunk;
+  float* const S = scratch;                                  // [V][R][D]
+  float* const PH = S + (long)V * R * D;                     // [nchunk][R][D]
+  float* const PT = PH + nchunk * R * D;                     // [nchunk][R][D]
+  DT_SWITCH(dtype, hipLaunchKernelGGL(node_init_bwd1a_kernel<T>, dim3((unsigned)nchunk, gy1), dim3(64), 0, (hipStream_t)stream,
+                                      (const T*)dnode, (const T*)feat, role_emb, verb_emb, order, seg, role_table, S, PH, PT,
+                                      d_verb_emb, B, R, D, V, NR, offs));
+  SR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(node_init_bwd1b_kernel, dim3((unsigned)V, gy2), dim3(64), 0, (hipStream_t)stream, role_emb, seg, role_table, S,
+                     (const float*)PH, (const float*)PT, d_verb_emb, R, D, NR);
   SR_CHECK_LAUNCH();
   hipLaunchKernelGGL(node_init_bwd2_kernel, dim3((unsigned)NR + 1, gy2), dim3(64), 0, (hipStream_t)stream, scratch, verb_emb,
                      inv_ptr, inv_slot, d_role_emb, R, D, NR);

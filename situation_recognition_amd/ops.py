@@ -459,7 +459,7 @@ def node_init_bwd(dnode, feat, role_emb, verb_emb, verbs, role_table, d_role_emb
     seg = torch.searchsorted(sorted_verbs, torch.arange(V + 1, device=verbs.device, dtype=verbs.dtype)).to(torch.int32)
     order = order.to(torch.int32)
     inv_ptr, inv_slot = _role_inverted_index(role_table, NR)
-    scratch = torch.empty((V * R, D), device=feat.device, dtype=torch.float32)
+    scratch = torch.empty(((V + 2 * ((B + 31) // 32)) * R, D), device=feat.device, dtype=torch.float32)   # srhip.h: S | PH | PT
     check(lib().sr_node_init_bwd(dnode.data_ptr(), feat.data_ptr(), role_emb.data_ptr(), verb_emb.data_ptr(), order.data_ptr(),
                                  seg.data_ptr(), role_table.data_ptr(), inv_ptr.data_ptr(), inv_slot.data_ptr(),
                                  scratch.data_ptr(), _f32(d_role_emb, "d_role_emb").data_ptr(),

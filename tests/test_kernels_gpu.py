@@ -270,6 +270,47 @@ def test_pools(ops, dtype):
     close(ops.avgpool(xh), x.float().mean((2, 3)), dtype)
 
 
+@pytest.mark.parametrize("layout", ["skewed", "aligned", "one_verb"])
+def test_node_init_backward_chunked_runs(ops, layout):
+    """sr_node_init_bwd sums a verb's images in 32-image chunks of the verb-sorted batch (one wave per chunk and column strip,
+    partials added in chunk order): runs inside one chunk, runs crossing chunk boundaries, runs that START on a boundary and span
+    whole chunks, absent verbs, and a batch that is almost all one verb (argmax of an untrained verb head) -- against autograd."""
+    R, D, V, NR = 6, 256, 12, 17
+    g = torch.Generator().manual_seed(3)
+    if layout == "skewed":
+        sizes = {0: 5, 2: 151, 3: 1, 5: 40, 6: 3, 9: 77, 11: 20}          # verbs 1, 4, 7, 8, 10 absent
+    elif layout == "aligned":
+        sizes = {1: 32, 2: 64, 4: 5, 5: 27, 7: 96, 8: 1}                    # runs that begin exactly on chunk boundaries
+    else:
+        sizes = {7: 290, 3: 1}
+    verbs = torch.cat([torch.full((n,), v) for v, n in sizes.items()])
+    verbs = verbs[torch.randperm(len(verbs), generator=g)]
+    B = len(verbs)
+    feat = rnd(B, D, dtype=torch.bfloat16, seed=1)
+    role_emb = rnd(NR + 1, D, seed=2); role_emb[NR] = 0
+    verb_emb = rnd(V, D, seed=3)
+    counts = torch.randint(1, R + 1, (V,), generator=g)
+    table = torch.full((V, R), NR, dtype=torch.int32)
+    for v in range(V):
+        k = int(counts[v])
+        table[v, :k] = torch.randperm(NR, generator=g)[:k].int()
+    re, ve = role_emb.clone().requires_grad_(True), verb_emb.clone().requires_grad_(True)
+    ref = F.relu(feat.float()[:, None] * re[table.long()[verbs]] * ve[verbs][:, None]).reshape(B * R, D)
+    dn = rnd(B * R, D, dtype=torch.bfloat16, seed=5)
+    ref.backward(dn.float())
+    re.grad[NR] = 0
+    dre, dve = torch.full((NR + 1, D), 5.0).cuda(), torch.full((V, D), -2.0).cuda()      # written in full
+    args = (dn.cuda(), feat.cuda(), role_emb.cuda(), verb_emb.cuda(), verbs.cuda(), table.cuda())
+    ops.node_init_bwd(*args, dre, dve)
+    close(dre, re.grad, torch.float32, k=40)
+    close(dve, ve.grad, torch.float32, k=40)
+    absent = [v for v in range(V) if v not in sizes]
+    assert float(dve[absent].abs().max()) == 0.0 and float(dre[NR].abs().max()) == 0.0
+    dre2, dve2 = torch.empty_like(dre), torch.empty_like(dve)
+    ops.node_init_bwd(*args, dre2, dve2)
+    assert torch.equal(dre, dre2) and torch.equal(dve, dve2)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_node_init_and_aggregate(ops, dtype):
     B, R, D, V, NR = 9, 6, 128, 7, 11
