@@ -428,22 +428,19 @@ def node_init_fwd(feat, role_emb, verb_emb, verbs, role_table, offs=None, rows=N
     return node
 
 
-_INV_INDEX = {}
-
-
 def _role_inverted_index(role_table, NR):
-    """CSR inverted index of the [V,R] role table: for every role id the slots v*R+r that hold it (static per encoder)."""
-    key = (role_table.data_ptr(), role_table._version, tuple(role_table.shape), NR)
-    hit = _INV_INDEX.get(key)
-    if hit is None:
+    """CSR inverted index of the [V,R] role table: for every role id the slots v*R+r that hold it (static per encoder).
+    Cached ON the tensor object (and its version counter), not in a table keyed by address: a freed table's address is reused
+    by the next allocation of that size, and a stale index silently mis-routes the role gradients."""
+    hit = getattr(role_table, "_sr_inv_index", None)
+    if hit is None or hit[0] != (role_table._version, NR, role_table.data_ptr()):
         flat = role_table.reshape(-1).long()
         slots = torch.argsort(flat, stable=True)
         ptrs = torch.zeros(NR + 2, dtype=torch.int64, device=role_table.device)
         ptrs[1:] = torch.cumsum(torch.bincount(flat, minlength=NR + 1), 0)
-        if len(_INV_INDEX) > 16:
-            _INV_INDEX.clear()
-        hit = _INV_INDEX[key] = (ptrs[: NR + 1].to(torch.int32).contiguous(), slots.to(torch.int32).contiguous())
-    return hit
+        hit = ((role_table._version, NR, role_table.data_ptr()), ptrs[: NR + 1].to(torch.int32).contiguous(), slots.to(torch.int32).contiguous())
+        role_table._sr_inv_index = hit
+    return hit[1], hit[2]
 
 
 def node_init_bwd(dnode, feat, role_emb, verb_emb, verbs, role_table, d_role_emb, d_verb_emb, offs=None):
