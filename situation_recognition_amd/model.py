@@ -1055,11 +1055,13 @@ class FCGGNN(nn.Module):
         """`denoms` [3] (data parallel): the global numbers of non-ignored targets per annotator; each term is then this rank's
         SUM over its targets divided by the global count (a rank without valid targets contributes exactly 0)."""
         L = self.encoder.get_num_labels()
-        logits = pred_nouns.float().transpose(1, 2)
-        loss = 0
-        for i in range(3):
-            if denoms is None:
-                loss = loss + nn.functional.cross_entropy(logits, gt_nouns[:, i], ignore_index=L)
-            else:
-                loss = loss + nn.functional.cross_entropy(logits, gt_nouns[:, i], ignore_index=L, reduction="sum") / denoms[i]
-        return loss
+        # The reference calls cross_entropy three times on the transposed [B, L, R] view (model.py:196-199): three strided
+        # log-softmax passes over the same 295 MB of logits (and three backward passes).  Same value from ONE row-wise
+        # log-softmax of the contiguous [B, R, L] logits and one gather of the three annotators' targets:
+        #     sum_i  sum_{valid (b, r)} -logp[b, r, t_i[b, r]] / count_i          (count_i = 0 -> nan, as cross_entropy gives)
+        logp = nn.functional.log_softmax(pred_nouns.float(), dim=-1)
+        t = gt_nouns.permute(0, 2, 1)                                      # [B, R, 3]
+        valid = t != L
+        picked = logp.gather(-1, t.clamp(max=L - 1))                       # [B, R, 3] (ignored slots: any in-range index, weight 0)
+        per = -(picked * valid).sum((0, 1))                                # [3]
+        return (per / (valid.sum((0, 1)) if denoms is None else denoms)).sum()
