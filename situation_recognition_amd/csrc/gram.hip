@@ -345,6 +345,46 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const TI* __restrict__
   if (mirror && gpart && (row >> 4) > (col >> 4)) out[(long)col * symC + row] = v;
 }
 
+// Both stages in one launch (what sr_bn_finalize_gram runs): a workgroup owns 64 consecutive elements; thread (group g of 16,
+// element e) folds partials g*per .. (g+1)*per-1 into fp64 (four interleaved sums, as above), the sixteen group sums meet in LDS
+// and are added in group order -- a fixed order for every element.  The last stage's mirror write (symC) is included.
+__global__ __launch_bounds__(1024) void gram_reduce_all_kernel(const float* __restrict__ in, long stride, int n, int per, long E,
+                                                               double* __restrict__ out, int symC) {
+  __shared__ double red[16][64];
+  const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long e = (long)blockIdx.x * 64 + el;
+  int row = 0, col = 0;
+  bool live = e < E;
+  const bool gpart = live && symC > 0 && e < (long)symC * symC;
+  if (gpart) {
+    row = (int)(e / symC); col = (int)(e - (long)row * symC);
+    if ((row >> 4) < (col >> 4)) live = false;          // (never written: see gram_reduce_kernel)
+  }
+  double v = 0.0;
+  if (live) {
+    const int t0 = g * per, t1 = min(n, t0 + per);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int t = t0;
+    for (; t + 4 <= t1; t += 4) {
+      s0 += (double)in[(long)t * stride + e];
+      s1 += (double)in[(long)(t + 1) * stride + e];
+      s2 += (double)in[(long)(t + 2) * stride + e];
+      s3 += (double)in[(long)(t + 3) * stride + e];
+    }
+    for (; t < t1; ++t) s0 += (double)in[(long)t * stride + e];
+    v = (s0 + s1) + (s2 + s3);
+  }
+  red[g][el] = v;
+  __syncthreads();
+  if (g != 0 || !live) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; q += 4) { a0 += red[q][el]; a1 += red[q + 1][el]; a2 += red[q + 2][el]; a3 += red[q + 3][el]; }
+  const double tot = (a0 + a1) + (a2 + a3);
+  out[e] = tot;
+  if (gpart && (row >> 4) > (col >> 4)) out[(long)col * symC + row] = tot;
+}
+
 // One workgroup (512 threads) per 8 output channels: s1 = w.cs, s2 = w G w in fp64, then the BatchNorm finalize of
 // bn_finalize_kernel (elementwise.hip) for those channels.  Thread (g, kk): rows l of eighth g of G, columns kk + 64u
 // (u < 4) -- the w[l][0..7] a step needs are wave-uniform LDS reads (broadcasts), and those were what bounded the first
@@ -377,16 +417,22 @@ __global__ __launch_bounds__(512) void gram_project_kernel(const double* __restr
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[u][j] = 0.0;
     const int kbase = kb + kk;                      // columns kbase + 64u; past C (C = 64, 128): read column kk again, weight 0
-    for (int l = g * lq; l < (g + 1) * lq; ++l) {
-      double gv[4];
+    // (rows four at a time: their 16 loads are issued together -- one row per trip left every trip waiting an L2 round trip,
+    //  20 us per launch for 134 MFLOP; lq = C / 8 is a multiple of 4 for every C served)
+    for (int l = g * lq; l < (g + 1) * lq; l += 4) {
+      double gv[4][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) gv[u] = G[(long)l * C + (kbase + 64 * u < C ? kbase + 64 * u : kk)];
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const double w = wl[l][j];
+        for (int u = 0; u < 4; ++u) gv[q][u] = G[(long)(l + q) * C + (kbase + 64 * u < C ? kbase + 64 * u : kk)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u][j] = fma(gv[u], w, a[u][j]);
-      }
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const double w = wl[l + q][j];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a[u][j] = fma(gv[q][u], w, a[u][j]);
+        }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -606,8 +652,14 @@ extern "C" int sr_bn_finalize_gram(const float* partials, int64_t npartials, int
   double* stageA = scratch + E;   // [chunks][E]; final fp64 G | colsum at scratch[0..E)
   const unsigned gx = (unsigned)((E + 255) / 256);
   const int symC = C <= 256 ? C : 0;       // (C = 512 runs as 2 x 2 panels of 256: all four blocks are computed)
-  hipLaunchKernelGGL(gram_reduce_kernel<float>, dim3(gx, chunks), dim3(256), 0, st, partials, E, (int)npartials, per, E, stageA, symC, 0);
-  hipLaunchKernelGGL(gram_reduce_kernel<double>, dim3(gx, 1), dim3(256), 0, st, (const double*)stageA, E, chunks, chunks, E, scratch, symC, 1);
+  if (chunks <= 16) {          // (up to 256 partials -- one per CU: every BatchNorm of a ResNet at any batch) both stages in one launch
+    const int per16 = (int)((npartials + 15) / 16);
+    hipLaunchKernelGGL(gram_reduce_all_kernel, dim3((unsigned)((E + 63) / 64)), dim3(1024), 0, st, partials, E, (int)npartials, per16, E,
+                       scratch, symC);
+  } else {
+    hipLaunchKernelGGL(gram_reduce_kernel<float>, dim3(gx, chunks), dim3(256), 0, st, partials, E, (int)npartials, per, E, stageA, symC, 0);
+    hipLaunchKernelGGL(gram_reduce_kernel<double>, dim3(gx, 1), dim3(256), 0, st, (const double*)stageA, E, chunks, chunks, E, scratch, symC, 1);
+  }
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   hipLaunchKernelGGL(gram_project_kernel, dim3((N + 7) / 8), dim3(512), 0, st, (const double*)scratch, (const double*)(scratch + (long)C * C),
                      (const bf16_t*)w, (long)ldw, C, N, 1.0 / (double)count, unbias, gamma, beta, running_mean, running_var, momentum, eps,
