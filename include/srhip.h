@@ -47,8 +47,9 @@ extern "C" {
 #define SR_ABI_VERSION 4
 int sr_abi_version(void);
 
-/* Launches that follow (from any thread) size their persistent grids for 1/share of the device's compute units (share 1..8;
- * default 1, or the SR_CU_SHARE environment variable): `share` streams that run the same kind of work side by side -- the two
+/* Launches that follow FROM THE CALLING THREAD size their persistent grids (and everything derived from the CU count: tile shapes,
+ * partial-statistics row counts returned by sr_conv_stats_rows / sr_gemm_stats_tiles) for 1/share of the device's compute units
+ * (share 1..8; default 1, or the SR_CU_SHARE environment variable): `share` streams that run the same kind of work side by side -- the two
  * backbones of FCGGNN.forward, reference model.py:159,116 -- then co-reside on disjoint CUs instead of each launching a
  * full-chip grid that queues behind the other's.  Returns the previous share, or SR_ERR_ARG. */
 int sr_set_cu_share(int share);

@@ -60,11 +60,14 @@ inline bool sr_set_dynamic_lds_tagged(const void* kernel, int bytes) {
 }
 // sr_set_cu_share (elementwise.hip): the persistent kernels size their grids for 1/share of the chip, so that the launches of
 // `share` concurrent streams co-reside on disjoint sets of CUs instead of queueing behind each other's full-chip grids.
-extern int sr_cu_share_value;
+// The value is thread-local (0 = the process default): everything derived from it -- grids, v3_cfg's tile choice, partial-statistics
+// row counts, Gram slice counts -- is consistent between a query and the launch it sizes as long as both come from one thread.
+extern const int sr_cu_share_default;
+extern thread_local int sr_cu_share_tls;
 inline int sr_num_cus() {
   static int cache[SR_MAX_DEV] = {};
   const int d = sr_cur_dev();
-  const int share = __atomic_load_n(&sr_cu_share_value, __ATOMIC_RELAXED);
+  const int share = sr_cu_share_tls > 0 ? sr_cu_share_tls : sr_cu_share_default;
   if (d < 0) return 256 / share;
   int n = __atomic_load_n(&cache[d], __ATOMIC_ACQUIRE);
   if (n <= 0) {

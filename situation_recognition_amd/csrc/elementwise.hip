@@ -395,10 +395,16 @@ __global__ void dropout_half_kernel(const T* __restrict__ x, T* __restrict__ y, 
 
 extern "C" int sr_abi_version(void) { return SR_ABI_VERSION; }
 
-int sr_cu_share_value = [] { const char* e = getenv("SR_CU_SHARE"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+// The share is PER CALLING THREAD (the process default comes from SR_CU_SHARE): a thread that sizes its grids for half the chip
+// -- FCGGNN.forward while its two backbone streams are being enqueued -- does not change the grids, tile shapes or partial-buffer
+// sizes of launches issued by any other thread (the autograd engine's, a data loader's).
+const int sr_cu_share_default = [] { const char* e = getenv("SR_CU_SHARE"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+thread_local int sr_cu_share_tls = 0;
 extern "C" int sr_set_cu_share(int share) {
   if (share < 1 || share > 8) return SR_ERR_ARG;
-  return __atomic_exchange_n(&sr_cu_share_value, share, __ATOMIC_RELAXED);
+  const int prev = sr_cu_share_tls > 0 ? sr_cu_share_tls : sr_cu_share_default;
+  sr_cu_share_tls = share;
+  return prev;
 }
 
 extern "C" int sr_stem_prep(const float* img, void* out, int B, int H, int W, int dtype, void* stream) {

@@ -27,6 +27,7 @@ struct ExpArgs {
   const float* escale; const float* bias;
   int M, N, K, relu;
   const float* in_scale; const float* in_shift;   // weight-stationary kernel only: A <- relu(A * in_scale[k] + in_shift[k]) on load
+  int plain_map;                                  // SR_WS_PLAIN_MAP=1 (A/B measurements): the round-3 block -> (column block, walker) map
 };
 
 template <int I, int N, typename F>
@@ -85,7 +86,17 @@ __device__ __forceinline__ void ws_body(const ExpArgs& p) {
   const int NWG = WN * 64;                       // columns per workgroup
   const int nh = p.N / NWG;                      // column blocks
   const int G = gridDim.x / nh;                  // row walkers per column block (the host makes the grid a multiple of nh)
-  const int half = blockIdx.x % nh, walker = blockIdx.x / nh;
+  // Two column blocks (N = 1024: layer3's expansion, 36 launches per pass) walk the SAME rows, i.e. both read every activation tile.
+  // With the plain map (half = block % 2) the two readers of a tile are neighbouring block ids, which the dispatcher deals to
+  // different XCDs (round robin over 8): the tile crossed the fabric twice -- the family's measured 1.11x of its algorithmic bytes
+  // (profiles/r03/conv_traffic_b6144.json).  Blocks b and b + 8 share an XCD, so within every group of 16 blocks the two halves of
+  // walker 8 g + x are the blocks 16 g + x and 16 g + 8 + x: the second read of a tile is served by that XCD's L2 (both walk the same
+  // tile sequence at the same pace, 16 KiB apart at most a few tiles).  Placement is a speed matter only: any map is correct.
+  int half = blockIdx.x % nh, walker = blockIdx.x / nh;
+  if (nh == 2 && (gridDim.x & 15) == 0 && !p.plain_map) {
+    half = (blockIdx.x >> 3) & 1;
+    walker = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+  }
   const int ntile = (p.M + TM - 1) / TM;
   const int my_tiles = walker < ntile ? (ntile - walker + G - 1) / G : 0;
   const int n0 = half * NWG + wn * 64;           // this wave's first column
@@ -312,6 +323,8 @@ int srx_conv1x1_expand(const sr_conv_args* a, long M, void* stream) {
   x.escale = a->escale; x.bias = a->bias;
   x.M = (int)M; x.N = a->Cout; x.K = a->Cin; x.relu = a->act == SR_ACT_RELU;
   x.in_scale = a->in_scale; x.in_shift = a->in_shift;
+  static const int plain_map = [] { const char* e = getenv("SR_WS_PLAIN_MAP"); return e && e[0] == '1' ? 1 : 0; }();
+  x.plain_map = plain_map;
   hipStream_t st = (hipStream_t)stream;
   if (ws_enabled() && (a->Cout == 256 || a->Cout == 512 || a->Cout == 1024)) {     // weight-stationary form
     SR_ROUTE(SR_ROUTE_WS);

@@ -81,8 +81,12 @@ __global__ __launch_bounds__(64) void node_init_bwd1a_kernel(const T* __restrict
                                                              const int32_t* __restrict__ offs) {
   constexpr int N = Vec16<T>::N;
   const int chunk = blockIdx.x, c0 = chunk * kChunk, c1 = min(B, c0 + kChunk);
-  const int d = (blockIdx.y * 64 + threadIdx.x) * N;
-  if (d >= D) return;
+  // Lanes past the last column strip stay ALIVE (their loads fall on column 0, their stores are predicated): the walk below reads
+  // the chunk's image indices out of the lanes 0 .. 31 with readlane, and an exited lane's registers were never written
+  // (D / N < 32 lanes -- bf16 D = 64, or D = 128 with B > 16 -- read garbage indices before this).
+  const int d_raw = (blockIdx.y * 64 + threadIdx.x) * N;
+  const bool live = d_raw < D;
+  const int d = live ? d_raw : 0;
   // the chunk's image indices and first node rows, one per lane (read by lane index below: no dependent loads in the walk)
   const int pos = c0 + (int)(threadIdx.x & (kChunk - 1));
   const int my_b = pos < c1 ? order[pos] : 0;
@@ -131,11 +135,11 @@ __global__ __launch_bounds__(64) void node_init_bwd1a_kernel(const T* __restrict
 #pragma unroll
         for (int k = 0; k < N; ++k) {
           dve[k] += acc[r][k] * ro[r][k];
-          dst[(long)r * D + d + k] = acc[r][k];
+          if (live) dst[(long)r * D + d + k] = acc[r][k];
         }
       }
     }
-    if (whole) {
+    if (whole && live) {
 #pragma unroll
       for (int k = 0; k < N; ++k) d_verb[(long)v * D + d + k] = dve[k];
     }

@@ -478,7 +478,7 @@ class resnet(nn.Module):
     # -- eval-mode pass replayed from a hipGraph (single-image inference is launch-bound: ~320 kernel launches of a few
     #    microseconds each; one graph launch replaces them)
     def _graph_forward(self, x):
-        key = (tuple(x.shape), x.dtype, self.dtype, self._weights_signature(), self._stats_epoch)
+        key = (tuple(x.shape), x.dtype, self.dtype, self._weights_signature(), self._stats_epoch, ops.cu_share())
         hit = self._graphs.get(key)
         if hit is None:
             self._forward_impl(x, 1)                        # eager warm-up: builds the folded packs, sets kernel attributes
@@ -503,7 +503,7 @@ class resnet(nn.Module):
         call with a given shape runs eagerly (that is the call's result) and only then captures -- capturing executes nothing, so
         the running statistics are not updated twice."""
         key = ("train", tuple(x.shape), x.dtype, self.dtype, self._weights_signature(buffers=False),
-               tuple(t.data_ptr() for t in self.model.buffers()), bn_updates)
+               tuple(t.data_ptr() for t in self.model.buffers()), bn_updates, ops.cu_share())
         hit = self._graphs.get(key)
         if hit is None:
             out = self._forward_impl(x, bn_updates)
@@ -982,6 +982,10 @@ class FCGGNN(nn.Module):
             side = self._side_streams.get(img.device)
             if side is None:
                 side = self._side_streams[img.device] = torch.cuda.Stream(device=img.device)
+            # (a CPU `gt_verb`, which the reference's predict_nouns accepts and moves itself, model.py:118-119: the copy is made here,
+            #  on the main stream, before the streams fork -- a copy issued on the side stream would not be ordered against main-stream users)
+            if not gt_verb.is_cuda:
+                gt_verb = gt_verb.to(device=img.device, dtype=torch.int64)
             # Both backbones take the same images: the layout kernel in front of the stem (fp32 NCHW or decoded uint8 -> padded bf16
             # NHWC4) runs once, on the main stream, and its output feeds both passes.
             share = self.convnet_verbs.dtype == self.convnet_nouns.dtype and not (self.convnet_verbs.use_graphs or self.convnet_nouns.use_graphs)

@@ -2,6 +2,7 @@
 allocates outputs with torch (device memory only) and enqueues the HIP kernel on the current stream.
 Nothing here computes on the CPU or with torch operators."""
 import ctypes as C
+import threading
 
 import torch
 
@@ -81,11 +82,22 @@ def gemm(pairs, N=None, bias=None, bias_scale=1.0, bias2=None, act=ACT_NONE, res
     return (out, out2) if two else out
 
 
+_CU_SHARE = threading.local()
+
+
 def set_cu_share(share):
-    """Persistent grids of the launches that follow are sized for 1/share of the chip (sr_set_cu_share); returns the previous value."""
+    """Persistent grids of the launches that follow FROM THIS THREAD are sized for 1/share of the chip (sr_set_cu_share); returns the
+    previous value."""
     rc = lib().sr_set_cu_share(int(share))
     check(min(rc, 0), "sr_set_cu_share")
+    _CU_SHARE.value = int(share)
     return rc
+
+
+def cu_share():
+    """The share this thread's launches are sized for (None = the library's default): part of the key of every captured hipGraph,
+    whose grids are baked in at capture time."""
+    return getattr(_CU_SHARE, "value", None)
 
 
 def stats_tiles(M, N):

@@ -128,7 +128,9 @@ class GradBucket:
 
         bucket.zero()              instead of optimizer.zero_grad()   (keeps .grad pointing into the buffer)
         loss.backward()            autograd accumulates into the views; when the last gradient of a bucket has been
-                                   written, its hook launches an asynchronous all-reduce(SUM) of that slice
+                                   written AND every earlier bucket has been launched, its hook launches an asynchronous
+                                   all-reduce(SUM) of that slice (same order of collectives on every rank, whatever order
+                                   autograd finishes them in)
         bucket.finish()            launches what is left (parameters that received no gradient stay zero) and waits
 
     Afterwards every rank holds the SUM of the ranks' gradients (`average=True`: the mean, for losses that are per-rank
@@ -166,6 +168,8 @@ class GradBucket:
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._pending = [len(b) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._next = 0                 # buckets [0, _next) have been launched: launches go out in bucket order on EVERY rank
+        self.launch_order = []         # bucket indices in the order their collectives were issued since the last zero() (tests)
         self._works = []
         self._hooks = []
         for p in self.params:
@@ -195,6 +199,8 @@ class GradBucket:
                 p.grad = self.views[i]
         self._pending = [len(b) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._next = 0
+        self.launch_order = []
         self._works = []
 
     def _span(self, b):
@@ -203,6 +209,7 @@ class GradBucket:
 
     def _launch(self, b):
         self._launched[b] = True
+        self.launch_order.append(b)
         lo, hi = self._span(b)
         if self.comm is not None:
             if self.comm.world > 1:
@@ -221,13 +228,20 @@ class GradBucket:
             raise RuntimeError("GradBucket: a gradient arrived for a bucket whose all-reduce was already launched -- "
                                "call zero() before every backward (gradient accumulation over several backwards is not supported)")
         self._pending[b] -= 1
-        if self._pending[b] == 0:
-            self._launch(b)
+        # Rank-invariant launch order.  The order in which autograd completes the buckets depends on how the forward was BUILT, and
+        # that can differ between ranks of one step (FCGGNN picks the packed-role / side-stream forms from its LOCAL batch, and
+        # shard sizes differ by one): ranks issuing differently sized collectives in different orders hang RCCL or sum the wrong
+        # slices.  So bucket b goes out only once buckets 0..b-1 have; a bucket that completes early waits for its predecessors
+        # (finish() launches the rest, in order).
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
 
     def finish(self):
-        for b in range(len(self.buckets)):
+        for b in range(self._next, len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
+        self._next = len(self.buckets)
         for w in self._works:
             w.wait()
         self._works = []

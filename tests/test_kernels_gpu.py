@@ -270,12 +270,14 @@ def test_pools(ops, dtype):
     close(ops.avgpool(xh), x.float().mean((2, 3)), dtype)
 
 
-@pytest.mark.parametrize("layout", ["skewed", "aligned", "one_verb"])
-def test_node_init_backward_chunked_runs(ops, layout):
+@pytest.mark.parametrize("layout,D", [("skewed", 256), ("aligned", 256), ("one_verb", 256), ("skewed", 64), ("aligned", 128)])
+def test_node_init_backward_chunked_runs(ops, layout, D):
     """sr_node_init_bwd sums a verb's images in 32-image chunks of the verb-sorted batch (one wave per chunk and column strip,
     partials added in chunk order): runs inside one chunk, runs crossing chunk boundaries, runs that START on a boundary and span
-    whole chunks, absent verbs, and a batch that is almost all one verb (argmax of an untrained verb head) -- against autograd."""
-    R, D, V, NR = 6, 256, 12, 17
+    whole chunks, absent verbs, and a batch that is almost all one verb (argmax of an untrained verb head) -- against autograd.
+    D = 64 / 128 (bf16): fewer column-strip lanes (8 / 16) than the 32 chunk positions a wave hands around with readlane -- lanes past
+    the last strip must stay alive for that (they used to exit before loading their image index)."""
+    R, V, NR = 6, 12, 17
     g = torch.Generator().manual_seed(3)
     if layout == "skewed":
         sizes = {0: 5, 2: 151, 3: 1, 5: 40, 6: 3, 9: 77, 11: 20}          # verbs 1, 4, 7, 8, 10 absent

@@ -39,8 +39,15 @@ class _Head(torch.nn.Module):
         self.verb_loss = types.MethodType(FCGGNN.verb_loss, self)
         self.nouns_loss = types.MethodType(FCGGNN.nouns_loss, self)
 
-    def forward(self, x):
+    def forward(self, x, nouns_first=False):
+        """`nouns_first`: build the noun branch's graph before the verb branch's, as FCGGNN.forward does when it queues the
+        ground-truth noun branch on the side stream (model.py `overlap_gt_branch`): autograd then completes the parameters'
+        gradients in a different order."""
         h = torch.tanh(self.shared(x))
+        if nouns_first:
+            pn = self.nouns_classifier(torch.tanh(self.shared(h[:, None, :] * self.role[None])))
+            pv = self.verb_classifier(torch.tanh(self.shared(x)))
+            return pv, pn
         pv = self.verb_classifier(h)
         pn = self.nouns_classifier(torch.tanh(self.shared(h[:, None, :] * self.role[None])))
         return pv, pn
@@ -76,11 +83,14 @@ def _worker(rank, world, port, out):
         bucket.zero()
         if step == 1:
             net.shared.weight.grad = None                               # a caller that reset a gradient: the hook adopts the new tensor
-        pv, pn = net(x[lo:hi])
+        # The ranks build their graphs in DIFFERENT orders (FCGGNN picks its packed-role / side-stream forms from the LOCAL batch,
+        # and shards straddle the threshold: 1024 vs 1023 images): the collectives must still go out in one order on every rank.
+        pv, pn = net(x[lo:hi], nouns_first=(rank == 1))
         loss, vl, nl, _ = parallel.global_batch_loss(net, pv, pn, verb[lo:hi], nouns[lo:hi])
         loss.backward()
         bucket.finish()
         assert all(bucket._launched) and float(net.unused.grad.abs().max()) == 0.0
+        assert bucket.launch_order == list(range(len(bucket.buckets))), bucket.launch_order
         share = torch.stack([vl.detach(), nl.detach()])
         dist.all_reduce(share)
         gn = torch.nn.utils.clip_grad_norm_(params, 1.0)
