@@ -54,7 +54,7 @@ struct KArgs {
   const void* zero_page;  // 256 zero bytes (device address of g_zero_page, resolved once on the host)
   void* trash_page;       // sink for out-of-range lanes' stores
   int debug;  // SR_GEMM_DEBUG bits (diagnostics, tools/ only): v2: 1 = skip MFMA, 2 = skip loads after the prologue; v3: 4 = in-kernel
-              // stamps (SR_STAMPS builds), 32 = lock-step loop instead of ping-pong, 128 = one-barrier rotated loop
+              // stamps (SR_STAMPS builds), 32 = lock-step loop instead of ping-pong
 };
 
 template <typename T> struct Frag;  // one 16-byte MFMA operand fragment
@@ -1071,87 +1071,7 @@ __device__ __forceinline__ void gemm_body_v3(const KArgs& p) {
 #endif
     Frag<T> a[FM], b[FN];
     int slot = 0, islot = D % NSLOT;
-    if (CFG == 4 && (p.debug & 128)) {
-      // ---- 256x256 tile, 8 waves, ONE barrier per step, wave group 1 ROTATED by half a step (SR_GEMM_DEBUG bit 128: round-4 experiment).
-      //   group 0 (wm = 0), step s:  wait(my pieces of s) ; X(s) ; L(s): 12 fragment reads, the 4 DMA pieces of step s+D ; M(s): 32 MFMAs
-      //   group 1 (wm = 1), step s:  wait(my pieces of s) ; X(s) ; M(s-1) ; L(s) ; lgkmcnt(0)
-      // After X(s) one wave of every SIMD multiplies (group 1: the step it read before the barrier) while the other loads, and then
-      // the roles swap WITHOUT a second barrier: a group that finishes its half early runs on into the other's instead of parking.
-      //   read-after-DMA : every wave waits for its own pieces of step s before X(s); both groups read step s after X(s).
-      //   DMA-after-read : the pieces of step s+D (slot of step s-1) are issued after X(s); group 0 read step s-1 before its M(s-1),
-      //                    group 1 in its L(s-1), drained (lgkmcnt 0) before X(s).
-      // Tile end: one barrier E (every wave has finished reading the last step's slot, which becomes the staging area), group 1
-      // multiplies its pending step, both run the epilogue; the next step's X orders the strips against the slot's refill.
-      auto mfma_block = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int k = 0; k < FN / 2; ++k) {
-#pragma unroll
-          for (int i = 0; i < FM; ++i) {
-            mma<T>(b[2 * k], a[i], acc[2 * k][i]);
-            mma<T>(b[2 * k + 1], a[i], acc[2 * k + 1][i]);
-          }
-        }
-        __builtin_amdgcn_s_setprio(0);
-      };
-      auto rot_wait = [&](int later) {                   // all but the `later` youngest DMA groups (+ an epilogue's S stores)
-        const bool st = since_epi > 0 && !two && S > 0;
-        if (since_epi > 0) --since_epi;
-        if (st) {
-          if (later >= 3) wait_vm<3 * L + S>(); else if (later == 2) wait_vm<2 * L + S>(); else if (later == 1) wait_vm<L + S>(); else wait_vm<S>();
-        } else {
-          if (later >= 3) wait_vm<3 * L>(); else if (later == 2) wait_vm<2 * L>(); else if (later == 1) wait_vm<L>(); else wait_vm<0>();
-        }
-      };
-      auto rot_step = [&](bool steady, int s, bool pend) {
-        if (steady) wait_vm<(D - 1) * L>(); else rot_wait(issued - s - 1);
-        __builtin_amdgcn_s_barrier();                    // X(s)
-        asm volatile("" ::: "memory");
-        if (wm == 1 && pend) mfma_block();               // group 1: M(s-1)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) b[j] = rdB(slot, j);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) a[i] = rdA(slot, i);
-        slot = slot + 1 == NSLOT ? 0 : slot + 1;
-        if (issued < total) {
-          st_slot = islot;
-#pragma unroll
-          for (int q = 0; q < L; ++q) issue_piece(q);
-          ++ld_kt; --seg_left; st_aoff += STEPB; st_woff += STEPB;
-          ++issued;
-          islot = islot + 1 == NSLOT ? 0 : islot + 1;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (wm == 0) mfma_block();                       // group 0: M(s)
-      };
-      int s = 0;
-      bool pend = false;
-      while (s < total) {
-        const bool steady = since_epi == 0 && issued - s == D && issued < total;
-        int n = 1;
-        if (steady) {
-          n = total - issued;
-          n = c_left < n ? c_left : n;
-          n = seg_left < n ? seg_left : n;
-        }
-        for (int i = 0; i < n; ++i) { rot_step(steady, s + i, pend); pend = true; }
-        s += n;
-        c_left -= n;
-        if (seg_left == 0) advance_tail();
-        if (c_left == 0) {
-          __builtin_amdgcn_s_barrier();                  // E: every wave has read the last step's slot
-          asm volatile("" ::: "memory");
-          if (wm == 1) mfma_block();                     // group 1: M(last)
-          pend = false;
-          stg_off = (slot == 0 ? NSLOT - 1 : slot - 1) * SLOT;
-          if constexpr (PLAIN) epilogue_plain(c_tile); else epilogue(c_tile);
-          since_epi = p.no_store ? 0 : D;
-          c_left = nkt;
-          c_tile += G;
-          clear_acc();
-        }
-      }
-    } else if (CFG == 4 && !(p.debug & 32)) {
+    if (CFG == 4 && !(p.debug & 32)) {
       // ---- 256x256 tile, 8 waves: the two wave groups (wm = 0 / 1: one wave of each per SIMD) run HALF A STEP apart.
       // A step is an L section (12 fragment reads, the 4 DMA pieces of step s+3, wait for the reads) and an M section
       // (32 back-to-back MFMAs at raised priority, no memory instruction), each closed by a barrier; group 1 starts one

@@ -627,55 +627,68 @@ class _GGNNFunction(torch.autograd.Function):
         (Wp, bp, Wz, bz, Uz, buz, Wr, br, Ur, bur, Wh, bh, Uh, buh) = params
         dt = h0.dtype
         g = lambda p: shadow.get(p, dt)
-        saved = []
-        h = h0.contiguous()
-        for _ in range(steps):
-            agg = h if verb else ops.aggregate(h, adj, idx, R, offs=offs)
-            n = ops.gemm([(agg, g(Wp))], bias=bp, bias_scale=1.0 if verb else float(R))
-            z = ops.gemm([(n, g(Wz)), (h, g(Uz))], bias=bz, bias2=buz, act=ops.ACT_SIGMOID)
-            r, rh = ops.gemm([(n, g(Wr)), (h, g(Ur))], bias=br, bias2=bur, act=ops.ACT_SIGMOID_MUL, aux1=h)
-            h_new, c = ops.gemm([(n, g(Wh)), (rh, g(Uh))], bias=bh, bias2=buh, act=ops.ACT_TANH_BLEND, aux1=h, aux2=z)
-            saved += [h, agg, n, z, r, rh, c]
-            h = h_new
+        M, D = h0.shape
+        # Everything the backward needs is kept STACKED over the steps ([T, M, D], step t = slice t; the GEMMs write their outputs
+        # straight into the slices): a weight gradient is then ONE TN GEMM over all T * M rows -- dW_z = [dz_0; ..; dz_T-1]^T [n_0; ..;
+        # n_T-1] -- instead of T launches of M rows each plus T partial reductions (round 4: at the 8-GPU share the verb path's M is
+        # 768 rows, six K-steps per slice: 70 such launches per step cost 3 ms for almost no arithmetic).
+        H = torch.empty((steps + 1, M, D), device=h0.device, dtype=dt)           # h_0 .. h_T
+        H[0].copy_(h0)
+        AGG = None if verb else torch.empty((steps, M, D), device=h0.device, dtype=dt)
+        N_, Z, R_, RH, C_ = (torch.empty((steps, M, D), device=h0.device, dtype=dt) for _ in range(5))
+        for t in range(steps):
+            h = H[t]
+            agg = h if verb else ops.aggregate(h, adj, idx, R, offs=offs, out=AGG[t])
+            n = ops.gemm([(agg, g(Wp))], bias=bp, bias_scale=1.0 if verb else float(R), out=N_[t])
+            z = ops.gemm([(n, g(Wz)), (h, g(Uz))], bias=bz, bias2=buz, act=ops.ACT_SIGMOID, out=Z[t])
+            _, rh = ops.gemm([(n, g(Wr)), (h, g(Ur))], bias=br, bias2=bur, act=ops.ACT_SIGMOID_MUL, aux1=h, out=R_[t], out2=RH[t])
+            ops.gemm([(n, g(Wh)), (rh, g(Uh))], bias=bh, bias2=buh, act=ops.ACT_TANH_BLEND, aux1=h, aux2=z, out=H[t + 1], out2=C_[t])
         ctx.meta = (R, verb, steps, shadow, adj, idx, offs)
+        saved = (H, N_, Z, R_, RH, C_) + (() if verb else (AGG,))
         ctx.save_for_backward(*saved, *params)
-        return h
+        return H[steps]
 
     @staticmethod
     def backward(ctx, dh):
         R, verb, steps, shadow, adj, idx, offs = ctx.meta
         tensors = ctx.saved_tensors
-        saved, params = tensors[: 7 * steps], tensors[7 * steps:]
+        ns = 6 if verb else 7
+        saved, params = tensors[:ns], tensors[ns:]
+        H, N_, Z, R_, RH, C_ = saved[:6]
+        AGG = None if verb else saved[6]
         (Wp, bp, Wz, bz, Uz, buz, Wr, br, Ur, bur, Wh, bh, Uh, buh) = params
-        dt = saved[0].dtype
+        dt = H.dtype
         kp = _kpad(dt)
         gT = lambda p: shadow.get(p, dt, transposed=True)
         D = Wp.shape[0]
         dev = dh.device
-        # Weight-gradient accumulators.  The four z/r matrices come out of ONE GEMM per step, [dz^T; dr^T] x [h^T; n^T]
-        # (4096 x 4096 = 256 tiles: the whole chip, instead of four 64-tile launches), the two candidate matrices out of
-        # dc^T x [n^T; (r*h)^T]; blocks are sliced apart at the end.
+        M = H.shape[1]
         # bf16, D a multiple of 256: dW = dY^T X straight from the row-major operands (`sr_gemm_tn`: transposed LDS reads, rows
-        # cut into slices so that each 2048 x 2048 gradient fills the chip) -- no transposed copies, no stacking.
+        # cut into slices so that each 2048 x 2048 gradient fills the chip) -- no transposed copies -- and ONE launch per weight matrix
+        # over the T stacked steps.  fp32 storage / narrow test models: NT GEMMs over transposed operands, step by step
+        # (the four z/r matrices out of ONE GEMM per step, [dz^T; dr^T] x [h^T; n^T]; the two candidate matrices out of dc^T x [n^T; (r*h)^T]).
         tn = dt == torch.bfloat16 and D % 256 == 0
         if tn:
-            gW = {k: torch.zeros(D, D, device=dev, dtype=torch.float32) for k in ("Wz", "Uz", "Wr", "Ur", "Wh", "Uh")}
+            DZ, DR, DC, DN = (torch.empty((steps, M, D), device=dev, dtype=dt) for _ in range(4))
         else:
             gZR = torch.zeros(2 * D, 2 * D, device=dev, dtype=torch.float32)      # rows: z | r ; cols: U (h) | W (n)
             gC = torch.zeros(D, 2 * D, device=dev, dtype=torch.float32)           # cols: W_h (n) | U_h (r*h)
-        gP = torch.zeros(D, D, device=dev, dtype=torch.float32)
+            gP = torch.zeros(D, D, device=dev, dtype=torch.float32)
         gb = {k: torch.zeros(D, device=dev, dtype=torch.float32) for k in ("p", "z", "r", "h")}
         dh = dh.contiguous()
         if dh.dtype != dt:
             dh = ops.cast(dh, dt)
-        M = saved[0].shape[0]
         Mp = (M + kp - 1) // kp * kp
         for t in reversed(range(steps)):
-            h, agg, n, z, r, rh, c = saved[7 * t: 7 * t + 7]
-            dc, dz, dacc = ops.gru_bwd1(dh, z, c, h)
+            h, n, z, r, rh, c = H[t], N_[t], Z[t], R_[t], RH[t], C_[t]
+            agg = h if verb else AGG[t]
+            if tn:
+                dc, dz, dacc = ops.gru_bwd1(dh, z, c, h, dc=DC[t], dz=DZ[t])
+            else:
+                dc, dz, dacc = ops.gru_bwd1(dh, z, c, h)
             drh = ops.gemm([(dc, gT(Uh))])
-            dr = ops.gru_bwd2(drh, r, h, dacc)                         # dacc += drh * r
-            dn = ops.gemm([(dc, gT(Wh)), (dz, gT(Wz)), (dr, gT(Wr))])
+            dr = ops.gru_bwd2(drh, r, h, dacc, dr=DR[t] if tn else None)     # dacc += drh * r
+            dn = ops.gemm([(dc, gT(Wh)), (dz, gT(Wz)), (dr, gT(Wr))], out=DN[t] if tn else None)
             dacc = ops.gemm([(dz, gT(Uz)), (dr, gT(Ur))], res=dacc, out=dacc)
             if verb:
                 dh = ops.gemm([(dn, gT(Wp))], res=dacc)
@@ -683,12 +696,6 @@ class _GGNNFunction(torch.autograd.Function):
                 dagg = ops.gemm([(dn, gT(Wp))])
                 dh = ops.aggregate(dagg, adj, idx, R, transpose=True, add=dacc, offs=offs)
             if tn:
-                ops.colsum(dz, gb["z"]); ops.colsum(dr, gb["r"]); ops.colsum(dc, gb["h"])
-                ops.colsum(dn, gb["p"], scale=1.0 if verb else float(R))
-                ops.gemm_tn(dz, n, gW["Wz"]); ops.gemm_tn(dz, h, gW["Uz"])
-                ops.gemm_tn(dr, n, gW["Wr"]); ops.gemm_tn(dr, h, gW["Ur"])
-                ops.gemm_tn(dc, n, gW["Wh"]); ops.gemm_tn(dc, rh, gW["Uh"])
-                ops.gemm_tn(dn, h if verb else agg, gP)
                 continue
             # transposed operands (dW = dY^T X as NT GEMMs); bias gradients (column sums) are reduced inside the transpose kernel
             YT = torch.empty((2, D, Mp), device=dev, dtype=dt)         # dz^T, dr^T
@@ -705,7 +712,18 @@ class _GGNNFunction(torch.autograd.Function):
             ops.gemm([(dcT, XT[1:3].view(2 * D, Mp))], res=gC, out=gC, out_f32=True)
             ops.gemm([(dnT, aggT)], res=gP, out=gP, out_f32=True)
         if tn:
-            grads = (gP, gb["p"], gW["Wz"], gb["z"], gW["Uz"], gb["z"].clone(), gW["Wr"], gb["r"], gW["Ur"], gb["r"].clone(),
+            TM = steps * M
+            flat = lambda x: x.view(TM, D)
+            Hs, Ns, RHs = H[:steps].reshape(TM, D), flat(N_), flat(RH)      # (H[:steps] is a contiguous prefix: a view)
+            dz, dr, dc, dn = flat(DZ), flat(DR), flat(DC), flat(DN)
+            ops.colsum(dz, gb["z"]); ops.colsum(dr, gb["r"]); ops.colsum(dc, gb["h"])
+            ops.colsum(dn, gb["p"], scale=1.0 if verb else float(R))
+            gW = {k: torch.empty(D, D, device=dev, dtype=torch.float32) for k in ("Wp", "Wz", "Uz", "Wr", "Ur", "Wh", "Uh")}
+            ops.gemm_tn(dz, Ns, gW["Wz"], accumulate=False); ops.gemm_tn(dz, Hs, gW["Uz"], accumulate=False)
+            ops.gemm_tn(dr, Ns, gW["Wr"], accumulate=False); ops.gemm_tn(dr, Hs, gW["Ur"], accumulate=False)
+            ops.gemm_tn(dc, Ns, gW["Wh"], accumulate=False); ops.gemm_tn(dc, RHs, gW["Uh"], accumulate=False)
+            ops.gemm_tn(dn, Hs if verb else flat(AGG), gW["Wp"], accumulate=False)
+            grads = (gW["Wp"], gb["p"], gW["Wz"], gb["z"], gW["Uz"], gb["z"].clone(), gW["Wr"], gb["r"], gW["Ur"], gb["r"].clone(),
                      gW["Wh"], gb["h"], gW["Uh"], gb["h"].clone())
             return (dh, None, None, None, None, None, None, None) + grads
         blk = lambda g_, i, j: g_[i * D:(i + 1) * D, j * D:(j + 1) * D].contiguous()

@@ -491,18 +491,26 @@ def aggregate(h, adj_table, verbs, R, transpose=False, add=None, out=None, offs=
     return out
 
 
-def gru_bwd1(dh, z, c, h):
-    require_gpu(dh, z, c, h)
-    dc, dz, dacc = torch.empty_like(dh), torch.empty_like(dh), torch.empty_like(dh)
+def gru_bwd1(dh, z, c, h, dc=None, dz=None):
+    """`dc`, `dz`: optional contiguous destinations (slices of the stacked [T, M, D] gradients the weight-gradient GEMMs read)."""
+    require_gpu(dh, z, c, h, dc, dz)
+    dc = torch.empty_like(dh) if dc is None else dc
+    dz = torch.empty_like(dh) if dz is None else dz
+    dacc = torch.empty_like(dh)
+    for t in (dc, dz):
+        if t.shape != dh.shape or t.dtype != dh.dtype or not t.is_contiguous():
+            raise L.SrError("gru_bwd1: bad destination")
     check(_timed("gru_bwd", 0, 7 * dh.numel() * dh.element_size(),       # reads dh, z, c, h; writes dc, dz, dacc
                  lambda: lib().sr_gru_bwd1(dh.data_ptr(), z.data_ptr(), c.data_ptr(), h.data_ptr(), dc.data_ptr(), dz.data_ptr(),
                                            dacc.data_ptr(), dh.numel(), dtype_code(dh.dtype), stream())), "sr_gru_bwd1")
     return dc, dz, dacc
 
 
-def gru_bwd2(drh, r, h, dh_acc):
-    require_gpu(drh, r, h, dh_acc)
-    dr = torch.empty_like(drh)
+def gru_bwd2(drh, r, h, dh_acc, dr=None):
+    require_gpu(drh, r, h, dh_acc, dr)
+    dr = torch.empty_like(drh) if dr is None else dr
+    if dr.shape != drh.shape or dr.dtype != drh.dtype or not dr.is_contiguous():
+        raise L.SrError("gru_bwd2: bad destination")
     check(_timed("gru_bwd", 0, 6 * drh.numel() * drh.element_size(),     # reads drh, r, h, dacc; writes dr, dacc
                  lambda: lib().sr_gru_bwd2(drh.data_ptr(), r.data_ptr(), h.data_ptr(), dr.data_ptr(), dh_acc.data_ptr(), drh.numel(),
                                            dtype_code(drh.dtype), stream())), "sr_gru_bwd2")
