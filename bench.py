@@ -94,22 +94,34 @@ def cpu_baseline(args):
     net = RefFCGGNN(enc, D, steps=args.T, backbone_factory=lambda: RefBackbone(args.backbone))
     net.train()
     opt = torch.optim.Adamax([p for p in net.parameters() if p.requires_grad], lr=0.002)
+    def sample(B, steps, warm):
+        g = torch.Generator().manual_seed(7)
+        img = torch.randn(B, 3, args.res, args.res, generator=g).clamp_(-2.2, 2.7)
+        verb = torch.randint(0, enc.get_num_verbs(), (B,), generator=g)
+        nouns = torch.randint(0, enc.get_num_labels(), (B, 3, enc.get_max_role_count()), generator=g)
+        for _ in range(warm):
+            log("cpu_baseline: warm-up step (batch %d, %d threads)" % (B, cores))
+            train_step(net, opt, img, verb, nouns)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            train_step(net, opt, img, verb, nouns)
+            log("cpu_baseline: batch %d, timed step %d/%d done" % (B, i + 1, steps))
+        dt = time.perf_counter() - t0
+        return B * steps / dt, dt
+
     B = args.cpu_batch
-    g = torch.Generator().manual_seed(7)
-    img = torch.randn(B, 3, args.res, args.res, generator=g).clamp_(-2.2, 2.7)
-    verb = torch.randint(0, enc.get_num_verbs(), (B,), generator=g)
-    nouns = torch.randint(0, enc.get_num_labels(), (B, 3, enc.get_max_role_count()), generator=g)
-    log("cpu_baseline: warm-up step (batch %d, %d threads)" % (B, cores))
-    train_step(net, opt, img, verb, nouns)                      # warm-up
-    t0 = time.perf_counter()
     steps = args.cpu_steps
-    for i in range(steps):
-        train_step(net, opt, img, verb, nouns)
-        log("cpu_baseline: timed step %d/%d done" % (i + 1, steps))
-    dt = time.perf_counter() - t0
-    return {"value": round(B * steps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle (fp32 CPU restatement of reference model.py) full training step, ResNet-%d + 6-role GGNN T=%d, "
-                      "batch %d, %d timed steps after 1 warm-up (%.1f s)" % (args.backbone, args.T, B, steps, dt)}
+    rate, dt = sample(B, steps, 1)
+    out = {"value": round(rate, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "oracle (fp32 CPU restatement of reference model.py) full training step, ResNet-%d + 6-role GGNN T=%d, "
+                     "batch %d, %d timed steps after 1 warm-up (%.1f s)" % (args.backbone, args.T, B, steps, dt)}
+    if args.cpu_batch2 > 0:
+        # the second size of SURVEY 8(d) / BASELINE.md (batch 256): ONE timed step, no warm-up of its own (the threads and the
+        # allocator are warm from the first sample; a 256-image step takes 20-25 s on 16 cores, so the default run stays bounded)
+        rate2, dt2 = sample(args.cpu_batch2, 1, 0)
+        out["value_batch%d" % args.cpu_batch2] = round(rate2, 3)
+        out["sample"] += "; value_batch%d: the same step at batch %d, 1 timed step (%.1f s)" % (args.cpu_batch2, args.cpu_batch2, dt2)
+    return out
 
 
 def spawn_ranks(args, argv):
@@ -158,6 +170,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch2", type=int, default=256, help="second CPU sample size (one timed step); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fp8", action="store_true",
@@ -211,6 +224,7 @@ def main():
     img, verb, nouns = synthetic_batch(enc, B, args.res, dev, seed_shift=rank)
 
     def step():
+        role_rows["last"] = []
         if bucket is None:
             opt.zero_grad(set_to_none=True)
         else:
@@ -229,6 +243,18 @@ def main():
         opt.step()
         return loss
 
+    # packed role rows (FCGGNN._use_packed): how many rows the two noun branches of a step really push through the GGNN and the
+    # classifier -- the predicted-verb branch of an untrained head collapses onto very few verbs, so its row count is whatever those
+    # verbs' role counts are; printed in `config` so that two runs are comparable
+    role_rows = {}
+    plan0 = net._pack_plan
+
+    def counting_plan(verbs, B_, R_):
+        out_ = plan0(verbs, B_, R_)
+        role_rows["last"] = role_rows.get("last", []) + [int(out_[1]) + 1]
+        return out_
+
+    net._pack_plan = counting_plan
     log("model + %d synthetic images per rank resident; warm-up" % B)
     for i in range(args.warmup):
         step()
@@ -265,6 +291,10 @@ def main():
                    "global_batch": args.global_batch, "per_gpu_batch": B, "parallelism": "dp%d" % world,
                    "backbone_weights": "shared (one pass serves both)" if args.shared_backbone else "two distinct backbones",
                    "backbone_launch": "hipGraph replay" if use_graphs else "eager",
+                   "role_rows_executed": ({"predicted_verb_branch": role_rows["last"][0], "ground_truth_branch": role_rows["last"][1],
+                                           "of_full_form": B * enc.get_max_role_count()} if len(role_rows.get("last", [])) == 2
+                                          else {"predicted_verb_branch": B * enc.get_max_role_count(),
+                                                "ground_truth_branch": B * enc.get_max_role_count(), "of_full_form": B * enc.get_max_role_count()}),
                    "final_loss": round(final_loss, 4)},
     }
 

@@ -134,6 +134,7 @@ int sr_conv_in_affine_supported(const sr_conv_args* a, int dtype);
 #define SR_ROUTE_C3D 18
 #define SR_ROUTE_STEM 19
 #define SR_ROUTE_C3D128 20
+#define SR_ROUTE_C3D256 21 /* conv3x3_c256_kernel (direct 3x3, 256 channels, 14 x 14 images) */
 int sr_conv_route(const sr_conv_args* a, int dtype);
 /* rows of `stats` this exact launch writes (the stem runs on a direct-convolution kernel with its own partial layout; every
  * other launch follows sr_gemm_stats_tiles(M, Cout)).  Fill the geometry fields of `a`; pointers are not read. */

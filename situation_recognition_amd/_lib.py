@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SR_LIB_PATH") or os.path.join(_HERE, "libsrhip.so")  
 
 ABI_VERSION = 4                  # include/srhip.h: SR_ABI_VERSION
 SR_F32, SR_BF16 = 0, 1
-ROUTE_WS, ROUTE_C3D, ROUTE_STEM, ROUTE_C3D128 = 16, 18, 19, 20     # sr_conv_route codes
+ROUTE_WS, ROUTE_C3D, ROUTE_STEM, ROUTE_C3D128, ROUTE_C3D256 = 16, 18, 19, 20, 21     # sr_conv_route codes
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SIGMOID_MUL, ACT_TANH_BLEND = range(6)
 _ERR = {-1: "SR_ERR_ARG (bad shape/alignment/null pointer)", -2: "SR_ERR_DTYPE", -3: "SR_ERR_LAUNCH",
         -4: "SR_ERR_UNSUPPORTED"}

@@ -127,6 +127,9 @@ bool srx_c3d_in_affine_ok(const sr_conv_args* a);
 int srx_c3d128_conv(const sr_conv_args* a, void* stream);
 int srx_c3d128_rows(const sr_conv_args* a);
 bool srx_c3d128_in_affine_ok(const sr_conv_args* a);
+int srx_c3d256_conv(const sr_conv_args* a, void* stream);     // c3d256.hip: direct 3x3, 256 channels, 14 x 14 images (layer3)
+int srx_c3d256_rows(const sr_conv_args* a);
+bool srx_c3d256_in_affine_ok(const sr_conv_args* a);
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }

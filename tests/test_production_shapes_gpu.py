@@ -66,20 +66,23 @@ def pack_w(w):                                        # [Cout,Cin,KH,KW] -> [Cou
 B14 = 1024                                            # 1024 x 14 x 14 = 200 704 output rows = 784 row tiles of 256
 
 
-def test_conv3x3_256_256_statistics_kernel(ops):
-    """layer3's 3x3 (35 launches per pass, 14 % of the step): `<bf16,bf16,4,7>` (one-pass raw + statistics epilogue) -- raw bf16
-    output + running BatchNorm partial sums over 3-4 tiles per workgroup; padding taps through out-of-range buffer loads.  Then the
+def test_conv3x3_generic_statistics_kernel(ops):
+    """The 3x3 the GENERIC implicit-GEMM kernel still carries in the benchmark: layer4's 512 -> 512 @7 (2 launches per pass; layer1-3's
+    stride-1 3x3s have direct kernels since rounds 2-4, c3d*.hip) -- `<bf16,bf16,4,7>` (one-pass raw + statistics epilogue): raw bf16
+    output + running BatchNorm partial sums over 3 tiles per workgroup; padding taps through out-of-range buffer loads.  Then the
     GENERAL statistics kernel `<bf16,bf16,4,1>` (statistics of conv + bias, masked edge path) on the same operands."""
-    Cc = 256
-    M = B14 * 196
+    from situation_recognition_amd import _lib
+    Cc, HH, BB = 512, 7, 4096
+    M = BB * HH * HH
     assert cfg(ops, M, Cc) == 4
-    x = rnd(B14, 14, 14, Cc, seed=1)
+    assert ops.conv_route(BB, HH, HH, Cc, Cc, 3, 1, 1, want_stats=True) == 4 == ops.conv_route(6144, HH, HH, Cc, Cc, 3, 1, 1, want_stats=True)
+    x = rnd(BB, HH, HH, Cc, seed=1)
     w = rnd(Cc, Cc, 3, 3, seed=2, scale=(Cc * 9) ** -0.5)
     y, stats = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, want_stats=True)
     ref = conv_ref(x, w, 3, 1)
     close(y.view(M, Cc), ref)
     cpu = F.conv2d(x[:2].float().cpu().permute(0, 3, 1, 2), w.float().cpu(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cc)
-    assert float((ref[: 2 * 196].cpu() - cpu).abs().max()) < 1e-4 * float(cpu.abs().max())
+    assert float((ref[: 2 * HH * HH].cpu() - cpu).abs().max()) < 1e-4 * float(cpu.abs().max())
     s1, s2 = stats[:, 0].double().sum(0), stats[:, 1].double().sum(0)
     r1, r2 = ref.double().sum(0), (ref.double() ** 2).sum(0)
     assert float((s1 - r1).abs().max()) < 1e-4 * float(ref.abs().sum(0).max())
@@ -561,3 +564,75 @@ def test_cu_share_changes_grids_not_results(ops):
     valid = torch.cat([ops.gram_valid_mask(256).reshape(-1), torch.ones(256, dtype=torch.bool)]).cuda()
     a, b = g1[:, valid].double().sum(0), g2[:, valid].double().sum(0)
     assert g2.shape[0] < g1.shape[0] and float(((a - b).abs() / a.abs().clamp_min(1.0)).max()) < 2e-5
+
+
+@pytest.mark.parametrize("B", [1, 3, 37, 300, 1100])
+def test_conv3x3_256_256_direct_kernel(ops, B):
+    """layer3's 3x3 (35 launches per pass, the largest item of the step) on the direct-convolution kernel (csrc/c3d256.hip: one image
+    per tile, the input staged in 32-channel slices that serve all nine taps, every wave streaming its own 64 weight rows through a
+    private LDS ring): train-mode form (raw output + BatchNorm partial sums; batches from a single tile to several tiles per workgroup,
+    so the rings and the chunk buffers wrap across tiles), statistics-only form and eval form (bias + ReLU) against F.conv2d in fp32
+    on the bf16-rounded operands; bit-reproducible.  (Reference call site model.py:35 -> torchvision Bottleneck.conv2 of layer3.)"""
+    from situation_recognition_amd import _lib
+    Cc, H = 256, 14
+    M = B * H * H
+    assert ops.conv_route(B, H, H, Cc, Cc, 3, 1, 1, want_stats=True) == _lib.ROUTE_C3D256 == ops.conv_route(6144, H, H, Cc, Cc, 3, 1, 1, want_stats=True)
+    assert ops.conv_route(B, H, H, Cc, Cc, 3, 1, 1, bias=True, relu=True) == _lib.ROUTE_C3D256
+    x = F.relu(rnd(B, H, H, Cc, seed=B)).to(BF)
+    w = rnd(Cc, Cc, 3, 3, seed=B + 1, scale=(Cc * 9) ** -0.5)
+    y, stats = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, want_stats=True)
+    assert stats.shape[0] == min(B, torch.cuda.get_device_properties(0).multi_processor_count)
+    ref4 = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1)
+    ref = ref4.reshape(M, Cc)
+    if not (y.float() - ref4).abs().max() <= tol(ref):
+        bad = ((y.float() - ref4).abs() > tol(ref)).nonzero()
+        pytest.fail("%d outputs off; first (image, row, column, channel): %s; channels hit: %s; pixels hit: %s" % (
+            len(bad), bad[:6].tolist(), sorted(set(bad[:, 3].tolist()))[:16], sorted(set((bad[:, 1] * 14 + bad[:, 2]).tolist()))[:20]))
+    close(y.view(M, Cc), ref)
+    _stats_close(stats, ref)
+    st2 = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, stats_only=True)
+    assert torch.equal(st2, stats)
+    bias = 0.3 * torch.randn(Cc, device="cuda")
+    y3 = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, bias=bias, relu=True)
+    close(y3.view(M, Cc), F.relu(ref + bias))
+    y4 = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1)
+    assert torch.equal(y4, y)
+    for _ in range(3):                                 # bit-reproducible (fixed summation order, no atomics)
+        yb, sb = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, want_stats=True)
+        assert torch.equal(yb, y) and torch.equal(sb, stats)
+
+
+@pytest.mark.parametrize("B", [2, 37, 600])
+def test_direct_256_3x3_normalises_its_input_on_load(ops, B):
+    """bn1 -> relu -> conv2 of a layer3 bottleneck without the normalised tensor (round 4: the last `bn_apply` sweep in front of a 3x3):
+    the 256-channel direct kernel applies scale / shift + ReLU to the NEXT channel slice's patch in LDS while the current slice
+    multiplies (pad pixels stay zero: the convolution pads the NORMALISED tensor).  Output and BatchNorm partial sums bit-identical to
+    the same kernel on the tensor bn_apply wrote, and within bf16 rounding of the fp32 reference; corners and edges on their own."""
+    Cc, H = 256, 14
+    y1 = rnd(B, H, H, Cc, seed=B + 3)
+    sc, sh = 0.5 + torch.rand(Cc, device="cuda"), 0.3 * torch.randn(Cc, device="cuda") + 0.2     # (relu(shift) != 0 on the pads if transformed)
+    w = rnd(Cc, Cc, 3, 3, seed=B + 4, scale=(Cc * 9) ** -0.5)
+    assert ops.conv_in_affine_supported(y1, Cc, 3, 1, 1, res=None, relu=False, want_stats=True)
+    lazy, st_l = ops.conv2d(y1, pack_w(w), Cc, 3, 1, 1, want_stats=True, in_affine=(sc, sh))
+    z1 = ops.bn_apply(y1, sc, sh, relu=True)
+    eager, st_e = ops.conv2d(z1, pack_w(w), Cc, 3, 1, 1, want_stats=True)
+    ref = F.conv2d(F.relu(y1.float() * sc + sh).to(BF).float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1)
+    if not torch.equal(lazy, eager):
+        bad = (lazy != eager).nonzero()
+        lines = ["%d differing outputs; first: " % len(bad)]
+        for b_, y_, x_, c_ in bad[:12].tolist():
+            lines.append("  out[%d,%d,%d,%d]: on-load %.6f  bn_apply-fed %.6f  fp32 reference %.6f"
+                         % (b_, y_, x_, c_, float(lazy[b_, y_, x_, c_]), float(eager[b_, y_, x_, c_]), float(ref[b_, y_, x_, c_])))
+        pytest.fail("\n".join(lines))
+    if not torch.equal(st_l, st_e):
+        bad = (st_l != st_e).nonzero()
+        pytest.fail("%d differing partial-statistics entries; first (row, which, channel): %s" % (len(bad), bad[:8].tolist()))
+    close(lazy.view(-1, Cc), ref.reshape(-1, Cc))
+    edge = torch.zeros(H, H, dtype=torch.bool, device="cuda")
+    edge[0], edge[-1], edge[:, 0], edge[:, -1] = True, True, True, True
+    close(lazy[:, edge], ref[:, edge], k=float(ref.abs().max() / ref[:, edge].abs().max()))
+    for _ in range(4):
+        again, st_a = ops.conv2d(y1, pack_w(w), Cc, 3, 1, 1, want_stats=True, in_affine=(sc, sh))
+        assert torch.equal(again, lazy) and torch.equal(st_a, st_l)
+    with pytest.raises(Exception):                                     # eval form (bias + ReLU): not served with an input affine
+        ops.conv2d(y1, pack_w(w), Cc, 3, 1, 1, bias=sh, relu=True, in_affine=(sc, sh))

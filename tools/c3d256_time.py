@@ -1,0 +1,36 @@
+"""Times layer3's 3x3 (256 -> 256 @14, batch 6144 by default) on the direct kernel (c3d256.hip): train-mode form, the same with BatchNorm +
+ReLU of its input applied on load, and -- for comparison -- what the two forms replace: SR_NO_C3_256=1 selects the generic kernel,
+which needs the `bn_apply` sweep in front.   usage: python tools/c3d256_time.py [batch]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from situation_recognition_amd import ops
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 6144
+dev, dt = "cuda", torch.bfloat16
+g = torch.Generator(device=dev).manual_seed(1)
+x = torch.randn(B, 14, 14, 256, device=dev, generator=g).to(dt)
+w = (torch.randn(256, 2304, device=dev, generator=g) * 2304 ** -0.5).to(dt)
+sc, sh = 0.5 + torch.rand(256, device=dev), 0.1 * torch.randn(256, device=dev)
+
+
+def timed(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+fl = 2.0 * B * 196 * 256 * 2304
+t_plain = timed(lambda: ops.conv2d(x, w, 256, 3, 1, 1, want_stats=True))
+out = "3x3 256->256 @14 batch %d route %s: raw+stats %.1f us (%.0f TFLOP/s)" % (B, ops.conv_route(B, 14, 14, 256, 256, 3, 1, 1, want_stats=True), t_plain, fl / t_plain / 1e6)
+if ops.conv_in_affine_supported(x, 256, 3, 1, 1, res=None, relu=False, want_stats=True):
+    t_in = timed(lambda: ops.conv2d(x, w, 256, 3, 1, 1, want_stats=True, in_affine=(sc, sh)))
+    out += " | BatchNorm on load %.1f us" % t_in
+else:
+    xb = x.clone()
+    t_bn = timed(lambda: ops.bn_apply(xb, sc, sh, relu=True, out=xb))
+    out += " | bn_apply sweep in front %.1f us -> %.1f us together" % (t_bn, t_bn + t_plain)
+print(out, flush=True)
