@@ -22,8 +22,8 @@
 //     & 3 -- the pixel's index at the IMAGE's pitch, halved: the same for all 13 fragments of a tap (16 i = 0 mod 8) -- 4.2 LDS cycles
 //     per ds_read_b128 over all fragments and taps (4 = conflict free; enumerated with the instruction's lane groups; with a patch pitch
 //     of 16 no key of this family gets below 7.2).  Weight-row chunk c of row n sits at c ^ (-(n >> 2) & 3), as in c3d128.hip;
-//   * epilogue: running BatchNorm partial sums per lane over ALL tiles of the workgroup (one reduction per kernel), or bias + ReLU (eval
-//     mode); bf16 through a per-wave staging strip, two 16-byte stores per lane and pixel fragment.
+//   * epilogue: BatchNorm partial sums folded per tile into a per-wave LDS row (one row of partial statistics per workgroup), or bias +
+//     ReLU (eval mode); bf16 through a per-wave staging strip, two 16-byte stores per lane and pixel fragment.
 // Same interface as the generic path (sr_conv2d); the partial-statistics row count comes from sr_conv_stats_rows.
 #include <stdlib.h>
 
@@ -56,7 +56,8 @@ constexpr int K6_PBUF = 4 * K6_NPW * 1024;                // 20 KiB per chunk bu
 constexpr int K6_D = 6;                                   // depth of a wave's weight ring (divides the 18 K-steps of a chunk pair: static slots)
 constexpr int K6_NKC = 9;                                 // K-steps per chunk (taps)
 constexpr int K6_WSTEP = 4096;                            // ring bytes per K-step and wave: 64 rows x 64 B
-constexpr int K6_WRING = 2 * K6_PBUF, K6_STG = K6_WRING + 4 * K6_D * K6_WSTEP, K6_VEC = K6_STG + 4 * 4096, K6_LDS = K6_VEC + 1024 + 2048;
+constexpr int K6_WRING = 2 * K6_PBUF, K6_STG = K6_WRING + 4 * K6_D * K6_WSTEP, K6_VEC = K6_STG + 4 * 4096, K6_STAT = K6_VEC + 1024 + 2048;
+constexpr int K6_LDS = K6_STAT + 4 * 512;               // ... | per-wave [2][64] running BatchNorm sums
 constexpr int K6_NST = 2 * K6_FP;                         // output stores per wave and tile
 constexpr int K6_OOB = (int)0x80000000;
 static_assert(K6_NP <= 4 * K6_NPW && (2 * K6_NKC) % K6_D == 0 && K6_LDS <= 160 * 1024, "tile / LDS budget");
@@ -170,12 +171,16 @@ __device__ __forceinline__ void k6_body(const K6Args& p) {
 
   char* const stg = smem + K6_STG + wave * 4096;        // two 2 KiB strips per wave (fragment i uses strip i & 1)
 
-  // statistics / bias of this lane's 4 x 4 output channels (couts 64 wave + 16 j + 4 fgrp + r)
-  float s1[4][4], s2[4][4], bv[4][4];
+  // bias of this lane's 4 x 4 output channels (couts 64 wave + 16 j + 4 fgrp + r).  The BatchNorm partial sums do NOT live in registers
+  // across the K loop (32 of them pushed the train-mode kernels into scratch, whose traffic the counted vmcnt waits cannot see): every
+  // tile's sums are folded (16-lane DPP sums, then LDS float adds by four lanes) into the wave's LDS row, written out once per kernel.
+  float bv[4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; bv[j][r] = 0.f; }
+    for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
+  float* const lstat = reinterpret_cast<float*>(smem + K6_STAT) + wave * 128;      // this wave's [2][64] running sums
+  lstat[lane] = 0.f; lstat[64 + lane] = 0.f;
 
   long tile = blockIdx.x;
   issue_patch(tile, 0, 0, tile < ntiles);
@@ -301,6 +306,11 @@ __device__ __forceinline__ void k6_body(const K6Args& p) {
                                                                            p.no_store ? 0 : K6_NPIX * K6_C * 2, 0x00020000);
     // fragment i: accumulators -> (bias, statistics, ReLU) -> bf16 -> strip i & 1; its strip reads are issued BEFORE fragment i + 1 is
     // converted and written (other strip), its stores behind that (one wave per SIMD: nothing else would cover the LDS round trip)
+    float s1[4][4], s2[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
     auto stage_frag = [&](int i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -343,20 +353,26 @@ __device__ __forceinline__ void k6_body(const K6Args& p) {
       for (int h = 0; h < 2; ++h)
         __builtin_amdgcn_raw_buffer_store_b128(val[h], srd_o, (16 * i + h * 8 + px8) * (K6_C * 2) + wave * 128 + cq8 * 16, 0, 0);
     }
+    if constexpr (ST) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t1 = k6row16_sum(s1[j][r]), t2 = k6row16_sum(s2[j][r]);
+          if (frow == 0) {
+            // (inline asm, like the strip stores: hipcc guards a visible LDS atomic with a wait for every vector-memory operation in flight)
+            const unsigned at = (unsigned)(uintptr_t)(lstat + 16 * j + 4 * fgrp + r);
+            asm volatile("ds_add_f32 %0, %1\n\tds_add_f32 %0, %2 offset:256" ::"v"(at), "v"(t1), "v"(t2) : "memory");
+          }
+        }
+    }
   }
   k6wait_vm<0>();
   if constexpr (ST) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float* const row = p.stats + (long)blockIdx.x * (2 * K6_C);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float t1 = k6row16_sum(s1[j][r]), t2 = k6row16_sum(s2[j][r]);
-        if (frow == 0) {
-          row[64 * wave + 16 * j + 4 * fgrp + r] = t1;
-          row[K6_C + 64 * wave + 16 * j + 4 * fgrp + r] = t2;
-        }
-      }
+    row[64 * wave + lane] = lstat[lane];
+    row[K6_C + 64 * wave + lane] = lstat[64 + lane];
   }
 }
 
