@@ -10,7 +10,8 @@
 //     pad pixels only -- zeros -- and are dropped by the output descriptor's range);
 //   * K order = (channel chunk, tap): the K loop walks 8 chunks of 32 input channels; a chunk's patch -- 16 rows x 18 padded pixels x
 //     64 B = 18 KiB -- is staged ONCE by LDS-DMA (pad pixels are out-of-range buffer loads: zeros) and serves all nine taps = nine
-//     K-steps; two chunk buffers alternate, chunk c + 1 lands while chunk c is multiplied (one workgroup barrier per chunk);
+//     K-steps; two chunk buffers alternate, chunk c + 1 lands while chunk c is multiplied (one workgroup barrier per chunk, one step
+//     before the chunk's end, so that the next chunk's first fragments are read ahead like any other step's);
 //   * FOUR waves, one per SIMD, split the OUTPUT CHANNELS: wave w owns couts 64w .. 64w+63 (4 weight fragments) for all 13 pixel
 //     fragments = 52 MFMAs (v_mfma_f32_16x16x32_bf16) per K-step against 13 + 4 fragment reads;
 //   * the weights (256 x 2304 bf16 = 1.18 MB, L2 resident) are streamed, each wave only ever reading its OWN 64 rows through a PRIVATE
@@ -87,10 +88,12 @@ __device__ __forceinline__ float k6row16_sum(float v) {
 // Vector-memory operations a wave has issued AFTER the weight pieces of the K-step it waits for.  The wait sits in step s (local index
 // sl = s % 9 inside its chunk), right behind that step's own weight issue (the pieces of step s + D), for the pieces of step s + 1,
 // which went out in step s + 1 - D:
-//   always           the 4 pieces of each of the D - 1 steps s + 2 .. s + D;
-//   sl <= D - 2      the 5 patch pieces of the next chunk, issued at the start of this chunk (behind the barrier, in front of step 9c's issue);
-//   first chunk of a tile, sl <= D - 2, not the workgroup's first tile: the previous tile's 26 output stores.
-template <int SL, bool STORES> constexpr int k6_younger() { return 4 * (K6_D - 1) + (SL <= K6_D - 2 ? K6_NPW + (STORES ? K6_NST : 0) : 0); }
+//   always                      the 4 pieces of each of the D - 1 steps s + 2 .. s + D;
+//   PATCH (sl = 8, 0, 1, 2, 3)  the 5 patch pieces issued at the start of the latest step with sl = 8 (behind the chunk barrier, in front
+//                               of that step's weight issue) -- except in the first chunk of a workgroup's first tile, whose patches
+//                               went out in the prologue, in front of every weight piece;
+//   STORES (sl = 0 .. 4 of a tile's first chunk, not the workgroup's first tile)  the previous tile's 26 output stores.
+template <bool PATCH, bool STORES> constexpr int k6_younger() { return 4 * (K6_D - 1) + (PATCH ? K6_NPW : 0) + (STORES ? K6_NST : 0); }
 
 // AFF: bias (+ ReLU) in the epilogue (eval mode: folded BatchNorm).  ST: BatchNorm partial statistics (train mode).
 // IN: the input is the RAW output of the preceding convolution; its BatchNorm + ReLU (in_scale, in_shift) is applied to the patch in LDS.
@@ -184,6 +187,7 @@ __device__ __forceinline__ void k6_body(const K6Args& p) {
 
   long tile = blockIdx.x;
   issue_patch(tile, 0, 0, tile < ntiles);
+  issue_patch(tile, 1, 1, tile < ntiles);
   k6wait_vm<0>();
   __syncthreads();                                      // bias / in-affine tables; my patch pieces have landed
   if (AFF) {
@@ -192,9 +196,11 @@ __device__ __forceinline__ void k6_body(const K6Args& p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[j][r] = lbias[64 * wave + 16 * j + 4 * fgrp + r];
   }
-  if (IN) {
+  if (IN) {                                             // chunk 0 of the first tile (chunk 1 follows inside the K loop, as every later chunk)
 #pragma unroll
     for (int i = 0; i < K6_NPW; ++i) normalise_piece(i, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
   }
   // the weight pieces of the first D K-steps (chunk 0, taps 0 .. 5)
 #pragma unroll
@@ -229,34 +235,39 @@ __device__ __forceinline__ void k6_body(const K6Args& p) {
       const int soff_cp = cp * 128, soff_nx = ((cp + 1) & 3) * 128;
       int zc;                                           // (an opaque 0 per trip, as `z` per tile: the 18 steps' chunk positions are invariant over
       asm volatile("v_mov_b32 %0, 0" : "=v"(zc));       //  the trips and would be hoisted out of the loop -- 36 live registers, spills)
-      const bool stores_behind = cp == 0 && !fst;       // (wave-uniform) the previous tile's stores sit between this chunk's first waits and their pieces
 
       auto kstep = [&](auto S18) {
         constexpr int s18 = decltype(S18)::value;       // 0 .. 17 inside the chunk pair
         constexpr int half = s18 / K6_NKC, sl = s18 % K6_NKC, tap = sl;
         constexpr int buf = half;
         const char* const pb = smem + buf * K6_PBUF;
-        if constexpr (sl == 0) {
-          // ---- chunk start: my normalised chunks of this buffer are written; everybody's pieces of it have landed (each wave's wait
-          // for the weights of this step, one step ago, covered its own, older, patch pieces) and everybody is done with the other buffer
-          if (IN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          const int nchunk = 2 * cp + half + 1;         // the chunk that follows (8 = the next tile's chunk 0)
-          if (nchunk < K6_NCH) issue_patch(tile, nchunk, buf ^ 1, true);
-          else issue_patch(tnext, 0, buf ^ 1, tnext < ntiles);
-        }
         // fragment addresses of this tap: chunk position fgrp ^ key, key = ((t + 14 r + q) >> 1) & 3 (16 i = 0 mod 8: one key per lane and tap)
         constexpr int tr = tap / 3, tq = tap % 3;
-        const int pos = ((fgrp ^ (((frow + zc + K6_W * tr + tq) >> 1) & 3)) << 4) + (tr * K6_PW + tq) * K6_CHB;
-        auto read_frag = [&](int i) { a[i] = *reinterpret_cast<const bf16x8_t*>(pb + base[i] + pos); };
-        if constexpr (sl == 0) {
+        if constexpr (s18 == 0) {                       // a trip's first step: nothing is read ahead across the loop's back edge (it would keep
+          const int pos = ((fgrp ^ (((frow + zc) >> 1) & 3)) << 4);   // 52 fragment registers alive across it and across the epilogue: spills)
 #pragma unroll
-          for (int i = 0; i < K6_FP; ++i) read_frag(i);
+          for (int i = 0; i < K6_FP; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(pb + base[i] + pos);
         }
-        // the tap that follows (within the chunk): its fragments are read into a[i] right behind the MFMAs that consumed a[i]
-        constexpr int ntr = (tap + 1) / 3, ntq = (tap + 1) % 3;
+        if constexpr (sl == K6_NKC - 1) {
+          // ---- the chunk barrier, ONE STEP BEFORE the chunk ends: my reads of this buffer have returned (the last tap's fragments were
+          // read a step ago) and my normalised chunks of the other buffer are written; behind the barrier that holds for everybody, so
+          // (1) this buffer may be refilled -- with the chunk after next --, and (2) the next chunk's first fragments can be read AHEAD,
+          // behind this step's MFMAs, instead of in the open at the start of the next chunk (13 reads of exposed LDS latency per chunk).
+          // Everybody's pieces of the next chunk have landed: each wave's wait in step sl = 4 (for weight pieces issued behind them)
+          // covered its own.
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          const int c2 = 2 * cp + half + 2;             // the chunk after next (8, 9 = the next tile's chunks 0, 1)
+          if (c2 < K6_NCH) issue_patch(tile, c2, buf, true);
+          else issue_patch(tnext, c2 - K6_NCH, buf, tnext < ntiles);
+        }
+        // the tap that follows: its fragments are read into a[i] right behind the MFMAs that consumed a[i] -- within the chunk from this
+        // buffer, in the first chunk's last step from the OTHER buffer (the second chunk's tap 0)
+        constexpr int ntap = (tap + 1) % K6_NKC, ntr = ntap / 3, ntq = ntap % 3;
+        const char* const pbn = smem + (sl + 1 < K6_NKC ? buf : buf ^ 1) * K6_PBUF;
         const int npos = ((fgrp ^ (((frow + zc + K6_W * ntr + ntq) >> 1) & 3)) << 4) + (ntr * K6_PW + ntq) * K6_CHB;
+        constexpr bool ahead = s18 != 17;
 #pragma unroll
         for (int i = 0; i < K6_FP; ++i) {
           __builtin_amdgcn_sched_barrier(0);
@@ -274,21 +285,29 @@ __device__ __forceinline__ void k6_body(const K6Args& p) {
             constexpr int k18 = s18 + K6_D;
             constexpr int kk = k18 % 18;
             issue_w(s18 % K6_D, (kk % K6_NKC) * 512 + (kk / K6_NKC) * 64 + (k18 < 18 ? soff_cp : soff_nx));
-            if (sl <= K6_D - 2) {
-              if (stores_behind && half == 0) k6wait_vm<k6_younger<sl, true>()>(); else k6wait_vm<k6_younger<sl, false>()>();
+            if constexpr (sl == K6_NKC - 1) {
+              k6wait_vm<k6_younger<true, false>()>();
+            } else if constexpr (sl <= 4) {
+              constexpr bool patch = sl <= 3;
+              if (half == 0 && cp == 0) {               // (wave-uniform) a tile's first chunk
+                if (fst) k6wait_vm<k6_younger<false, false>()>(); else k6wait_vm<k6_younger<patch, true>()>();
+              } else {
+                k6wait_vm<k6_younger<patch, false>()>();
+              }
             } else {
-              k6wait_vm<k6_younger<sl, false>()>();
+              k6wait_vm<k6_younger<false, false>()>();
             }
             read_b((s18 + 1) % K6_D, bb[(s18 + 1) & 1]);
           }
-          if constexpr (sl + 1 < K6_NKC) a[i] = *reinterpret_cast<const bf16x8_t*>(pb + base[i] + npos);
-          // the next chunk's patch, landed (it is older than the weight pieces waited for in step sl = D - 1): one or two pieces per step
-          if constexpr (IN && sl >= K6_D) {
+          if constexpr (ahead) a[i] = *reinterpret_cast<const bf16x8_t*>(pbn + base[i] + npos);
+          // the next chunk's patch has landed (it is older than the weight pieces waited for in step sl = 4): its pieces are normalised
+          // in steps 5, 6, 7 -- in front of the barrier of step 8
+          if constexpr (IN && sl >= 5 && sl <= 7) {
             if (i == 4) {
               const int nchunk = (2 * cp + half + 1) & 7;
-              if constexpr (sl == K6_D) { normalise_piece(0, nchunk, buf ^ 1); normalise_piece(1, nchunk, buf ^ 1); }
-              if constexpr (sl == K6_D + 1) { normalise_piece(2, nchunk, buf ^ 1); normalise_piece(3, nchunk, buf ^ 1); }
-              if constexpr (sl == K6_D + 2) normalise_piece(4, nchunk, buf ^ 1);
+              if constexpr (sl == 5) { normalise_piece(0, nchunk, buf ^ 1); normalise_piece(1, nchunk, buf ^ 1); }
+              if constexpr (sl == 6) { normalise_piece(2, nchunk, buf ^ 1); normalise_piece(3, nchunk, buf ^ 1); }
+              if constexpr (sl == 7) normalise_piece(4, nchunk, buf ^ 1);
             }
           }
         }
