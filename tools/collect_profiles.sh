@@ -4,7 +4,7 @@
 #   under the profiler and without it, and the per-shape table of one backbone pass.
 # usage: bash tools/collect_profiles.sh r02
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r04}
 R=$GRAFT_REPO_ROOT; [ -n "$R" ] || R=$PWD
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
