@@ -88,12 +88,14 @@ __device__ __forceinline__ float k6row16_sum(float v) {
 // Vector-memory operations a wave has issued AFTER the weight pieces of the K-step it waits for.  The wait sits in step s (local index
 // sl = s % 9 inside its chunk), right behind that step's own weight issue (the pieces of step s + D), for the pieces of step s + 1,
 // which went out in step s + 1 - D:
-//   always                      the 4 pieces of each of the D - 1 steps s + 2 .. s + D;
+//   always                      the 4 pieces of each of the D - 2 steps s + 2 .. s + D - 1 (the pieces of step s + D go out BEHIND the wait,
+//                               one per three pixel fragments: four LDS-DMA issues in a row stall the matrix pipe -- 1177 -> 1152 us;
+//                               spreading the five patch pieces of the barrier step the same way gained nothing);
 //   PATCH (sl = 8, 0, 1, 2, 3)  the 5 patch pieces issued at the start of the latest step with sl = 8 (behind the chunk barrier, in front
 //                               of that step's weight issue) -- except in the first chunk of a workgroup's first tile, whose patches
 //                               went out in the prologue, in front of every weight piece;
 //   STORES (sl = 0 .. 4 of a tile's first chunk, not the workgroup's first tile)  the previous tile's 26 output stores.
-template <bool PATCH, bool STORES> constexpr int k6_younger() { return 4 * (K6_D - 1) + (PATCH ? K6_NPW : 0) + (STORES ? K6_NST : 0); }
+template <bool PATCH, bool STORES> constexpr int k6_younger() { return 4 * (K6_D - 2) + (PATCH ? K6_NPW : 0) + (STORES ? K6_NST : 0); }
 
 // AFF: bias (+ ReLU) in the epilogue (eval mode: folded BatchNorm).  ST: BatchNorm partial statistics (train mode).
 // IN: the input is the RAW output of the preceding convolution; its BatchNorm + ReLU (in_scale, in_shift) is applied to the patch in LDS.
@@ -161,6 +163,9 @@ __device__ __forceinline__ void k6_body(const K6Args& p) {
     wvo[j] = ((64 * wave + 16 * j + n) * (9 * K6_C) + cd * 8) * 2;
   }
   const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, K6_C * 9 * K6_C * 2, 0x00020000);
+  auto issue_w1 = [&](int slot, int j, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (__attribute__((address_space(3))) void*)(wring + slot * K6_WSTEP + j * 1024), 16, wvo[j], soff, 0, 0);
+  };
   auto issue_w = [&](int slot, int soff) {   // slot = compile time at every call site; soff = tap * 512 + chunk * 64 (scalar)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -279,12 +284,14 @@ __device__ __forceinline__ void k6_body(const K6Args& p) {
             for (int j = 0; j < 4; ++j) k6mma(acc[i][j], bb[s18 & 1][j], a[i]);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (i == 0) {
-            // the weight pieces of step s + D go out (slot (s18 + D) % D = s18 % D: its fragments are in registers), then the wave waits for
-            // ITS pieces of step s + 1 and reads their four fragments
+          if (i == 1 || i == 4 || i == 7 || i == 10) {
+            // one weight piece of step s + D (slot (s18 + D) % D = s18 % D: its fragments are in registers)
             constexpr int k18 = s18 + K6_D;
             constexpr int kk = k18 % 18;
-            issue_w(s18 % K6_D, (kk % K6_NKC) * 512 + (kk / K6_NKC) * 64 + (k18 < 18 ? soff_cp : soff_nx));
+            issue_w1(s18 % K6_D, (i - 1) / 3, (kk % K6_NKC) * 512 + (kk / K6_NKC) * 64 + (k18 < 18 ? soff_cp : soff_nx));
+          }
+          if (i == 0) {
+            // the wave waits for ITS weight pieces of step s + 1 and reads their four fragments
             if constexpr (sl == K6_NKC - 1) {
               k6wait_vm<k6_younger<true, false>()>();
             } else if constexpr (sl <= 4) {
@@ -303,12 +310,9 @@ __device__ __forceinline__ void k6_body(const K6Args& p) {
           // the next chunk's patch has landed (it is older than the weight pieces waited for in step sl = 4): its pieces are normalised
           // in steps 5, 6, 7 -- in front of the barrier of step 8
           if constexpr (IN && sl >= 5 && sl <= 7) {
-            if (i == 4) {
-              const int nchunk = (2 * cp + half + 1) & 7;
-              if constexpr (sl == 5) { normalise_piece(0, nchunk, buf ^ 1); normalise_piece(1, nchunk, buf ^ 1); }
-              if constexpr (sl == 6) { normalise_piece(2, nchunk, buf ^ 1); normalise_piece(3, nchunk, buf ^ 1); }
-              if constexpr (sl == 7) normalise_piece(4, nchunk, buf ^ 1);
-            }
+            const int nchunk = (2 * cp + half + 1) & 7;
+            if (i == 3) normalise_piece(sl == 5 ? 0 : (sl == 6 ? 2 : 4), nchunk, buf ^ 1);
+            if (i == 8 && sl < 7) normalise_piece(sl == 5 ? 1 : 3, nchunk, buf ^ 1);
           }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -40,7 +40,9 @@ for B in (96, 768):
     x256, x1024 = t(B, 14, 14, 256), t(B, 14, 14, 1024)
     w33, w3, w1 = t(256, 9 * 256, scale=.03), t(1024, 256, scale=.06), t(256, 1024, scale=.03)
     sc, sh = torch.rand(1024, device=dev), torch.rand(1024, device=dev)
-    bad += screen("B=%d 3x3 256->256 + stats" % B, lambda: ops.conv2d(x256, w33, 256, 3, 1, 1, want_stats=True))
+    bad += screen("B=%d 3x3 256->256 @14 + stats (direct kernel, c3d256.hip)" % B, lambda: ops.conv2d(x256, w33, 256, 3, 1, 1, want_stats=True))
+    x512, w512 = t(4 * B, 7, 7, 512), t(512, 9 * 512, scale=.02)
+    bad += screen("B=%d 3x3 512->512 @7 + stats (generic 256x256 ping-pong kernel)" % (4 * B), lambda: ops.conv2d(x512, w512, 512, 3, 1, 1, want_stats=True))
     bad += screen("B=%d 1x1 256->1024 scale/shift/res/relu" % B, lambda: ops.conv2d(x256, w3, 1024, 1, 1, 0, bias=sh, escale=sc, res=x1024, relu=True))
     bad += screen("B=%d 1x1 1024->256 + stats" % B, lambda: ops.conv2d(x1024, w1, 256, 1, 1, 0, want_stats=True))
     bad += screen("B=%d gram 256" % B, lambda: gm(ops.gram(x256.view(-1, 256)), 256))
@@ -56,6 +58,7 @@ for B in (96, 768):
     x128 = t(B, 28, 28, 128); w128 = t(128, 9 * 128, scale=.04)
     bad += screen("B=%d 3x3 128->128 @28 (direct kernel, c3d128.hip)" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True))
     bad += screen("B=%d 3x3 128->128 @28 direct, BN on load" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True, in_affine=(s2[:128].contiguous(), h2[:128].contiguous())))
+    bad += screen("B=%d 3x3 256->256 @14 direct, BN on load (c3d256.hip)" % B, lambda: ops.conv2d(x256, w33, 256, 3, 1, 1, want_stats=True, in_affine=(s2, h2)))
     x128b = t(B, 24, 24, 128)
     bad += screen("B=%d 3x3 128->128 @24 (256x128 tiles)" % B, lambda: ops.conv2d(x128b, w128, 128, 3, 1, 1, want_stats=True))
     bad += screen("B=%d gram 128 / bn_gram 128" % B, lambda: (gm(ops.gram(x128.view(-1, 128)), 128), gm(ops.bn_gram(x128.view(-1, 128), s2[:128].contiguous(), h2[:128].contiguous()), 128)))
