@@ -121,6 +121,9 @@ def cpu_baseline(args):
         rate2, dt2 = sample(args.cpu_batch2, 1, 1)
         out["value_batch%d" % args.cpu_batch2] = round(rate2, 3)
         out["sample"] += "; value_batch%d: the same step at batch %d, 1 timed step after 1 warm-up (%.1f s)" % (args.cpu_batch2, args.cpu_batch2, dt2)
+    else:
+        out["sample"] += ("; the second size of SURVEY 8(d), batch 256, is measured with --cpu-batch2 256 (profiles/r04/bench_b6144.json: "
+                          "4.4 images/sec on that box's 16 cores, where this sample gave 7.7-10.0)")
     return out
 
 
@@ -170,7 +173,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--cpu-batch2", type=int, default=256, help="second CPU sample size (one timed step); 0 = off")
+    ap.add_argument("--cpu-batch2", type=int, default=0,
+                    help="second CPU sample size (SURVEY 8d: 256; one timed step after one warm-up: 2 x 60 s on a 16-core box, so it is "
+                         "off in the default run and on in tools/collect_profiles.sh, whose line is committed under profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fp8", action="store_true",

@@ -21,7 +21,7 @@ cd $R
 python3 tools/pmc_summarize.py $(find $O/trace -name "*kernel_trace.csv" | head -1) $(find $O/fetch -name "*counter_collection.csv" | head -1) \
         $(find $O/write -name "*counter_collection.csv" | head -1) $O b6144
 cp $(find $O/trace -name "*agent_info.csv" | head -1) $O/agent_info.csv 2>/dev/null
-timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 > $O/bench_b6144.json 2> $O/bench_b6144.err; echo "bench rc=$?"
+timeout -k 10 500 python3 bench.py --steps 10 --warmup 3 --cpu-batch2 256 > $O/bench_b6144.json 2> $O/bench_b6144.err; echo "bench rc=$?"
 timeout -k 10 300 python3 tools/layer_breakdown.py 6144 > $O/layer_breakdown_b6144.txt 2>&1
 # the other per-GPU shares of the global batch (strong scaling: 2 / 4 / 8 ranks), config 5 (fp8 3x3 convolutions, T = 8, batch 8192) and its
 # bf16 twin, the CPU baseline at batch 256 (BASELINE.md plan), a kernel trace at the 8-GPU share
