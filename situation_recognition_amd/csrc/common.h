@@ -123,13 +123,13 @@ int srx_stem_rows(const sr_conv_args* a);
 int srx_c3d_conv(const sr_conv_args* a, void* stream);
 int srx_c3d_rows(const sr_conv_args* a);
 bool srx_c3d_in_affine_ok(const sr_conv_args* a);
-// direct 3x3 convolution of the 128-channel layer on 28 x 28 images (c3d128.hip); same convention
-int srx_c3d128_conv(const sr_conv_args* a, void* stream);
-int srx_c3d128_rows(const sr_conv_args* a);
-bool srx_c3d128_in_affine_ok(const sr_conv_args* a);
-int srx_c3d256_conv(const sr_conv_args* a, void* stream);     // c3d256.hip: direct 3x3, 256 channels, 14 x 14 images (layer3)
+// direct 3x3 convolutions over 32-channel patch slices (c3ds.hip); same convention
+int srx_c3d256_conv(const sr_conv_args* a, void* stream);     // c3ds.hip: direct 3x3 over 32-channel patch slices, 256 channels, 14 x 14 images (layer3)
 int srx_c3d256_rows(const sr_conv_args* a);
 bool srx_c3d256_in_affine_ok(const sr_conv_args* a);
+int srx_c3d128s_conv(const sr_conv_args* a, void* stream);    // c3ds.hip: the same kernel for 128 channels, 28 x 28 images (layer2)
+int srx_c3d128s_rows(const sr_conv_args* a);
+bool srx_c3d128s_in_affine_ok(const sr_conv_args* a);
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }

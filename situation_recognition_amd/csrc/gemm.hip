@@ -1504,7 +1504,7 @@ extern "C" int sr_conv_stats_rows(const sr_conv_args* a, int dtype) {
     if (dtype == SR_BF16 && use_v3()) {
       int r = srx_c3d_rows(a);
       if (r != SR_ERR_UNSUPPORTED) return r;
-      r = srx_c3d128_rows(a);
+      r = srx_c3d128s_rows(a);
       if (r != SR_ERR_UNSUPPORTED) return r;
       r = srx_c3d256_rows(a);
       if (r != SR_ERR_UNSUPPORTED) return r;
@@ -1518,7 +1518,7 @@ extern "C" int sr_conv_stats_rows(const sr_conv_args* a, int dtype) {
 extern "C" int sr_conv_in_affine_supported(const sr_conv_args* a, int dtype) {
   if (!a || a->B <= 0 || a->stride <= 0 || dtype != SR_BF16 || !use_v3() || a->stem) return 0;
   const long Ho = (a->H + 2 * a->pad - a->KH) / a->stride + 1, Wo = (a->W + 2 * a->pad - a->KW) / a->stride + 1;
-  return (srx_conv1x1_in_affine_ok(a, (long)a->B * Ho * Wo) || srx_c3d_in_affine_ok(a) || srx_c3d128_in_affine_ok(a) || srx_c3d256_in_affine_ok(a)) ? 1 : 0;
+  return (srx_conv1x1_in_affine_ok(a, (long)a->B * Ho * Wo) || srx_c3d_in_affine_ok(a) || srx_c3d128s_in_affine_ok(a) || srx_c3d256_in_affine_ok(a)) ? 1 : 0;
 }
 
 thread_local int sr_route_probe = 0;
@@ -1607,7 +1607,7 @@ extern "C" int sr_conv2d(const sr_conv_args* a, int dtype, void* stream) {
     if (rc != SR_ERR_UNSUPPORTED) return rc;
     rc = srx_c3d_conv(a, stream);
     if (rc != SR_ERR_UNSUPPORTED) return rc;
-    rc = srx_c3d128_conv(a, stream);
+    rc = srx_c3d128s_conv(a, stream);
     return rc != SR_ERR_UNSUPPORTED ? rc : srx_c3d256_conv(a, stream);
   }
   if (dtype == SR_BF16 && use_v3()) {     // output-heavy 1x1 convolutions: the kernel that overlaps K loop and epilogue (expand.hip)
@@ -1615,9 +1615,9 @@ extern "C" int sr_conv2d(const sr_conv_args* a, int dtype, void* stream) {
     if (rc != SR_ERR_UNSUPPORTED) return rc;
     rc = srx_c3d_conv(a, stream);          // the 64-channel 3x3 layer: direct convolution, weights in registers (c3d.hip)
     if (rc != SR_ERR_UNSUPPORTED) return rc;
-    rc = srx_c3d128_conv(a, stream);       // the 128-channel 3x3 layer on 28 x 28 images: direct convolution, weights streamed per wave (c3d128.hip)
+    rc = srx_c3d128s_conv(a, stream);      // the 128-channel 3x3 layer on 28 x 28 images: direct convolution over 32-channel patch slices (c3ds.hip)
     if (rc != SR_ERR_UNSUPPORTED) return rc;
-    rc = srx_c3d256_conv(a, stream);       // the 256-channel 3x3 layer on 14 x 14 images: direct convolution over 32-channel patch slices (c3d256.hip)
+    rc = srx_c3d256_conv(a, stream);       // the 256-channel 3x3 layer on 14 x 14 images: direct convolution over 32-channel patch slices (c3ds.hip)
     if (rc != SR_ERR_UNSUPPORTED) return rc;
   }
   k.kp[0].A = a->x; k.kp[0].W = a->w; k.kp[0].lda = 0; k.kp[0].ldw = k.kp[0].K;

@@ -445,9 +445,10 @@ def test_generic_residual_epilogue_512_2048_and_stride2_downsample(ops):
 
 @pytest.mark.parametrize("B", [1, 3, 37, 300, 1100])
 def test_conv3x3_128_128_direct_kernel(ops, B):
-    """layer2's 3x3 (7 launches per pass) on the direct-convolution kernel (csrc/c3d128.hip: four image rows per tile, patch staged
-    once, every wave streaming its own 32 weight rows through a private LDS ring): train-mode form (raw output + BatchNorm partial
-    sums; batches from less than one tile per workgroup to 30 tiles per workgroup, so the weight ring wraps across tiles),
+    """layer2's 3x3 (7 launches per pass) on the direct-convolution kernel (csrc/c3ds.hip, the channel-slice kernel of layer3 instantiated
+    for 128 channels @28: fourteen image rows per tile, the input staged in 32-channel slices, every wave streaming its own 32 weight rows
+    through a private LDS ring): train-mode form (raw output +
+    BatchNorm partial sums; batches from less than one tile per workgroup to 9 tiles per workgroup, so the rings wrap across tiles),
     statistics-only form and eval form (bias + ReLU) against F.conv2d in fp32 on the bf16-rounded operands; bit-reproducible."""
     from situation_recognition_amd import _lib
     Cc, H = 128, 28
@@ -457,7 +458,7 @@ def test_conv3x3_128_128_direct_kernel(ops, B):
     x = F.relu(rnd(B, H, H, Cc, seed=B)).to(BF)
     w = rnd(Cc, Cc, 3, 3, seed=B + 1, scale=(Cc * 9) ** -0.5)
     y, stats = ops.conv2d(x, pack_w(w), Cc, 3, 1, 1, want_stats=True)
-    assert stats.shape[0] == min(B * 7, torch.cuda.get_device_properties(0).multi_processor_count)
+    assert stats.shape[0] == min(B * 2, torch.cuda.get_device_properties(0).multi_processor_count)      # (14-row tiles: two per image)
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1).reshape(M, Cc)
     close(y.view(M, Cc), ref)
     _stats_close(stats, ref)

@@ -1,4 +1,4 @@
-"""Times layer3's 3x3 (256 -> 256 @14, batch 6144 by default) on the direct kernel (c3d256.hip): train-mode form, the same with BatchNorm +
+"""Times layer3's 3x3 (256 -> 256 @14, batch 6144 by default) on the direct kernel (c3ds.hip): train-mode form, the same with BatchNorm +
 ReLU of its input applied on load, and -- for comparison -- what the two forms replace: SR_NO_C3_256=1 selects the generic kernel,
 which needs the `bn_apply` sweep in front.   usage: python tools/c3d256_time.py [batch]"""
 import os, sys

@@ -56,7 +56,7 @@ for B in (96, 768):
     bad += screen("B=%d 3x3 64->64 (direct kernel, c3d.hip)" % B, lambda: ops.conv2d(x64, w64, 64, 3, 1, 1, want_stats=True))
     bad += screen("B=%d 3x3 64->64 direct, BN on load" % B, lambda: ops.conv2d(x64, w64, 64, 3, 1, 1, want_stats=True, in_affine=(s2[:64].contiguous(), h2[:64].contiguous())))
     x128 = t(B, 28, 28, 128); w128 = t(128, 9 * 128, scale=.04)
-    bad += screen("B=%d 3x3 128->128 @28 (direct kernel, c3d128.hip)" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True))
+    bad += screen("B=%d 3x3 128->128 @28 (direct kernel, c3ds.hip)" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True))
     bad += screen("B=%d 3x3 128->128 @28 direct, BN on load" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True, in_affine=(s2[:128].contiguous(), h2[:128].contiguous())))
     bad += screen("B=%d 3x3 256->256 @14 direct, BN on load (c3d256.hip)" % B, lambda: ops.conv2d(x256, w33, 256, 3, 1, 1, want_stats=True, in_affine=(s2, h2)))
     x128b = t(B, 24, 24, 128)

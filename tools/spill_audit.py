@@ -8,7 +8,7 @@ import os, re, subprocess, sys, tempfile
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "situation_recognition_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=400000", "--cuda-device-only", "-S"]
-files = sys.argv[1:] or ["gemm.hip", "c3d.hip", "c3d128.hip", "expand.hip", "gram.hip", "fp8.hip", "stem.hip"]
+files = sys.argv[1:] or ["gemm.hip", "c3d.hip", "c3ds.hip", "expand.hip", "gram.hip", "fp8.hip", "stem.hip"]
 
 
 def demangle(names):
