@@ -88,7 +88,8 @@ int sr_gemm(const sr_gemm_args* a, int dtype, void* stream);
 int sr_gemm_stats_tiles(int M, int N);   /* rows of `stats` sr_gemm / sr_conv2d will write for (M, N) */
 /* Which tile shape sr_gemm / sr_conv2d will run an (M, N) launch on: 4 = 256x256 (8 waves, half-step ping-pong loop),
  * 2 = 256x128, 1 = 256x64 (4 waves, two workgroups per CU), 0 = the 128-byte-step fallback kernels.  `linear` != 0: epilogue
- * is SR_ACT_NONE / SR_ACT_RELU.  Introspection for tests and profiles (a parity test states which kernel it covered). */
+ * is SR_ACT_NONE / SR_ACT_RELU; the fused GRU epilogues (`linear` == 0) run on 4, or on 2 when the 256x256 tiles of the launch
+ * would cover at most half of the CUs.  Introspection for tests and profiles (a parity test states which kernel it covered). */
 int sr_gemm_tile_cfg(int M, int N, int linear, int out_16bit);
 /* Diagnostic only (synchronises!): copies the in-kernel cycle stamps of the last v3 GEMM launched with
  * SR_GEMM_DEBUG=4 to host memory: [256 blocks][8 waves][8] uint64 (0 vmcnt wait, 1 barrier, 2 DMA issue, 3 MFMA, 4 epilogue, 5 steps). */

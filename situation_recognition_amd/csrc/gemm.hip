@@ -1383,8 +1383,8 @@ int launch_v3(const KArgs& k_in, hipStream_t st) {
       if (!sr_set_dynamic_lds<&conv_igemm_v3_kernel<T, TO, WN, 0>>((int)lds)) return SR_ERR_LAUNCH;
       hipLaunchKernelGGL((conv_igemm_v3_kernel<T, TO, WN, 0>), dim3(grid), dim3(NTHR), lds, st, k);
     }
-  } else if constexpr (WN <= 2) {
-    // narrow tiles: linear epilogue only (caller guarantees)
+  } else if constexpr (WN == 1) {
+    // 256x64 tiles: linear epilogue only (caller guarantees)
     rc = k.stats ? launch_v3e<T, TO, WN, 1>(k, grid, lds, st)
                  : (sizeof(TO) == 2 && k.res ? launch_v3e<T, TO, WN, (sizeof(TO) == 2 ? 6 : 0)>(k, grid, lds, st) : launch_v3e<T, TO, WN, 0>(k, grid, lds, st));
   } else {
@@ -1405,7 +1405,8 @@ int launch_v3(const KArgs& k_in, hipStream_t st) {
 }
 
 // Which v3 tile shape serves (M, N)?  4: 256x256 (8 waves), 2: 256x128, 1: 256x64 (both 4 waves, two workgroups per CU), 0: not v3.
-// Only linear epilogues have the narrow shapes.  sr_gemm_stats_tiles() must agree with this, so it depends on M, N and the calling
+// The 256x64 shape is instantiated for linear epilogues only; the GRU gate epilogues have 256x128 besides 256x256 (round 4: the
+// small-batch launches of the GGNN).  sr_gemm_stats_tiles() must agree with this, so it depends on M, N and the calling
 // thread's CU share (sr_set_cu_share: thread-local, so a query and the launch it sizes see the same value) alone.
 inline int v3_cfg(long M, int N, bool linear) {
   if (!use_v3()) return 0;
@@ -1429,7 +1430,13 @@ inline int v3_cfg(long M, int N, bool linear) {
     }
     return 4;
   }
-  return N > 128 ? 4 : 0;
+  if (N <= 128) return 0;
+  // GRU gate epilogues: 256x128 tiles when every one of them still gets a CU of its own (the verb path of an 8-GPU share: 768 rows are 24
+  // tiles of 256 x 256 on 256 CUs).  Between half a round and a full one the narrow tiles do not pay: two of them sharing a CU take as
+  // long as the one wide tile they replace (SR_GEMM_GATE_NARROW=2 forces them there for the A/B, =0 switches them off).
+  static const int gate_narrow = [] { const char* e = getenv("SR_GEMM_GATE_NARROW"); return e ? atoi(e) : 1; }();
+  const long tw = gm * ((N + 255) / 256);
+  return (gate_narrow == 2 ? tw < cus : (gate_narrow == 1 && 2 * tw <= cus)) ? 2 : 4;
 }
 
 

@@ -158,13 +158,19 @@ def test_conv1x1_1024_256_statistics_kernel(ops):
     close(y2.view(-1, Cout), ref[: Br * 196])
 
 
-@pytest.mark.parametrize("M", [6144, 36864 + 100])
+@pytest.mark.parametrize("M", [6144, 36864 + 100, 768 + 37])
 def test_gemm_2048_all_epilogues_on_the_ping_pong_kernel(ops, M):
-    """GGNN shapes (reference model.py:64,75,80-84): N = K = 2048, M = the verb path's 6144 rows (96 tiles) and the noun
-    path's 36 864 (+100: a ragged last tile), 1-3 operand pairs, all five epilogues of `gemm_nt_v3_kernel<bf16,bf16,4,*>`."""
+    """GGNN shapes (reference model.py:64,75,80-84): N = K = 2048, M = the verb path's 6144 rows (192 tiles) and the noun
+    path's 36 864 (+100: a ragged last tile), 1-3 operand pairs, all five epilogues of `gemm_nt_v3_kernel<bf16,bf16,4,*>`.
+    M = 805 (the verb path of an 8-GPU share, ragged): 32 tiles of 256 x 256 would occupy an eighth of the chip, so the gate epilogues run
+    on the 256 x 128 instantiations `gemm_nt_v3_kernel<bf16,bf16,2,{2,3,4,5}>` (two operand pairs, two outputs) and the linear ones on
+    256 x 64."""
     D = 2048
-    for lin in (True, False):
-        assert cfg(ops, M, D, lin) == 4
+    if M > 4096:
+        for lin in (True, False):
+            assert cfg(ops, M, D, lin) == 4
+    else:
+        assert cfg(ops, M, D, False) == 2 and cfg(ops, M, D, True) in (1, 2)
     n, h, rh = rnd(M, D, seed=1), rnd(M, D, seed=2), rnd(M, D, seed=3)
     Ws = [rnd(D, D, seed=10 + i, scale=0.6 * D ** -0.5) for i in range(3)]
     b1, b2 = 0.3 * torch.randn(D, device="cuda"), 0.3 * torch.randn(D, device="cuda")
