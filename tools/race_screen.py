@@ -40,7 +40,7 @@ for B in (96, 768):
     x256, x1024 = t(B, 14, 14, 256), t(B, 14, 14, 1024)
     w33, w3, w1 = t(256, 9 * 256, scale=.03), t(1024, 256, scale=.06), t(256, 1024, scale=.03)
     sc, sh = torch.rand(1024, device=dev), torch.rand(1024, device=dev)
-    bad += screen("B=%d 3x3 256->256 @14 + stats (direct kernel, c3d256.hip)" % B, lambda: ops.conv2d(x256, w33, 256, 3, 1, 1, want_stats=True))
+    bad += screen("B=%d 3x3 256->256 @14 + stats (direct kernel, c3ds.hip)" % B, lambda: ops.conv2d(x256, w33, 256, 3, 1, 1, want_stats=True))
     x512, w512 = t(4 * B, 7, 7, 512), t(512, 9 * 512, scale=.02)
     bad += screen("B=%d 3x3 512->512 @7 + stats (generic 256x256 ping-pong kernel)" % (4 * B), lambda: ops.conv2d(x512, w512, 512, 3, 1, 1, want_stats=True))
     bad += screen("B=%d 1x1 256->1024 scale/shift/res/relu" % B, lambda: ops.conv2d(x256, w3, 1024, 1, 1, 0, bias=sh, escale=sc, res=x1024, relu=True))
@@ -58,7 +58,7 @@ for B in (96, 768):
     x128 = t(B, 28, 28, 128); w128 = t(128, 9 * 128, scale=.04)
     bad += screen("B=%d 3x3 128->128 @28 (direct kernel, c3ds.hip)" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True))
     bad += screen("B=%d 3x3 128->128 @28 direct, BN on load" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True, in_affine=(s2[:128].contiguous(), h2[:128].contiguous())))
-    bad += screen("B=%d 3x3 256->256 @14 direct, BN on load (c3d256.hip)" % B, lambda: ops.conv2d(x256, w33, 256, 3, 1, 1, want_stats=True, in_affine=(s2, h2)))
+    bad += screen("B=%d 3x3 256->256 @14 direct, BN on load (c3ds.hip)" % B, lambda: ops.conv2d(x256, w33, 256, 3, 1, 1, want_stats=True, in_affine=(s2, h2)))
     x128b = t(B, 24, 24, 128)
     bad += screen("B=%d 3x3 128->128 @24 (256x128 tiles)" % B, lambda: ops.conv2d(x128b, w128, 128, 3, 1, 1, want_stats=True))
     bad += screen("B=%d gram 128 / bn_gram 128" % B, lambda: (gm(ops.gram(x128.view(-1, 128)), 128), gm(ops.bn_gram(x128.view(-1, 128), s2[:128].contiguous(), h2[:128].contiguous()), 128)))
@@ -68,6 +68,9 @@ n, h, W = t(M, 2048), t(M, 2048), t(2048, 2048, scale=.02)
 U = t(2048, 2048, scale=.02); b1, b2 = torch.randn(2048, device=dev), torch.randn(2048, device=dev)
 bad += screen("GRU gate GEMM 2 pairs sigmoid", lambda: ops.gemm([(n, W), (h, U)], bias=b1, bias2=b2, act=ops.ACT_SIGMOID))
 bad += screen("GRU gate GEMM sigmoid*h", lambda: ops.gemm([(n, W), (h, U)], bias=b1, bias2=b2, act=ops.ACT_SIGMOID_MUL, aux1=h))
+ns, hs, zs = n[:805], h[:805], torch.rand(805, 2048, device=dev).to(dt)      # 256 x 128 tiles (launches covering at most half the CUs)
+bad += screen("GRU gate GEMM sigmoid*h, 805 rows (256x128 tiles)", lambda: ops.gemm([(ns, W), (hs, U)], bias=b1, bias2=b2, act=ops.ACT_SIGMOID_MUL, aux1=hs))
+bad += screen("GRU gate GEMM tanh & blend, 805 rows (256x128 tiles)", lambda: ops.gemm([(ns, W), (hs, U)], bias=b1, bias2=b2, act=ops.ACT_TANH_BLEND, aux1=hs, aux2=zs))
 out = torch.zeros(2048, 2048, device=dev)
 bad += screen("TN GEMM 2048x2048 K=36864", lambda: ops.gemm_tn(n, h, out, accumulate=False))
 print("TOTAL differing runs:", bad)
