@@ -128,14 +128,14 @@ int sr_conv_in_affine_supported(const sr_conv_args* a, int dtype);
  * no pointer is dereferenced -- x / w / y must still be non-null and 16-byte aligned).  Returns a negative SR_ERR_* code the launch
  * itself would return, or: 0 / 1 / 2 / 4 = the generic implicit-GEMM kernel on the tile shape sr_gemm_tile_cfg reports;
  * SR_ROUTE_WS = conv1x1_ws_kernel (weight-stationary output-heavy 1x1),
- * SR_ROUTE_C3D = conv3x3_c64_kernel (direct 3x3, 64 channels), SR_ROUTE_C3D128 = conv3x3_c128_kernel (direct 3x3, 128 channels),
+ * SR_ROUTE_C3D = conv3x3_c64_kernel (direct 3x3, 64 channels), SR_ROUTE_C3D128 = conv3x3_slices_kernel<KsL2> (direct 3x3, 128 channels, 28 x 28 images),
  * SR_ROUTE_STEM = stem_conv_kernel (direct 7x7/2 stem).
  * Introspection for the parity tests: a test at a reduced batch asserts that it covered the kernel the benchmark batch runs. */
 #define SR_ROUTE_WS 16
 #define SR_ROUTE_C3D 18
 #define SR_ROUTE_STEM 19
 #define SR_ROUTE_C3D128 20
-#define SR_ROUTE_C3D256 21 /* conv3x3_c256_kernel (direct 3x3, 256 channels, 14 x 14 images) */
+#define SR_ROUTE_C3D256 21 /* conv3x3_slices_kernel<KsL3> (direct 3x3, 256 channels, 14 x 14 images) */
 int sr_conv_route(const sr_conv_args* a, int dtype);
 /* rows of `stats` this exact launch writes (the stem runs on a direct-convolution kernel with its own partial layout; every
  * other launch follows sr_gemm_stats_tiles(M, Cout)).  Fill the geometry fields of `a`; pointers are not read. */

@@ -575,7 +575,7 @@ def test_cu_share_changes_grids_not_results(ops):
 
 @pytest.mark.parametrize("B", [1, 3, 37, 300, 1100])
 def test_conv3x3_256_256_direct_kernel(ops, B):
-    """layer3's 3x3 (35 launches per pass, the largest item of the step) on the direct-convolution kernel (csrc/c3d256.hip: one image
+    """layer3's 3x3 (35 launches per pass, the largest item of the step) on the direct-convolution kernel (csrc/c3ds.hip: one image
     per tile, the input staged in 32-channel slices that serve all nine taps, every wave streaming its own 64 weight rows through a
     private LDS ring): train-mode form (raw output + BatchNorm partial sums; batches from a single tile to several tiles per workgroup,
     so the rings and the chunk buffers wrap across tiles), statistics-only form and eval form (bias + ReLU) against F.conv2d in fp32

@@ -1,5 +1,5 @@
 // What does `buffer_load_dwordx4 ... lds` write for lanes whose address is out of the descriptor's range?  Every kernel that
-// zero-fills padding through the loader (gemm.hip rows past M / N and padding taps, c3d.hip / c3d128.hip pad pixels and the rows
+// zero-fills padding through the loader (gemm.hip rows past M / N and padding taps, c3d.hip / c3ds.hip pad pixels and the rows
 // above / below an image, gram.hip rows past a slice) relies on the answer being "sixteen zero bytes, for every such lane, also when
 // the WHOLE wave is out of range and when num_records is 0".  Three launches over an LDS image pre-filled with 0xdeadbeef:
 //   mixed : lanes 0-31 in range, 32-39 marker offset 0x80000000, 40-47 in range, 48-63 beyond num_records by a plain offset
