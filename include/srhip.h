@@ -43,8 +43,10 @@ extern "C" {
 #define SR_ACT_TANH_BLEND 5  /* C2 = c = tanh(v); C = (1-aux2)*aux1 + aux2*c  (GRU candidate+blend) */
 
 /* Bumped on every incompatible change of a signature or struct below (2: sr_conv_args grew in_scale / in_shift, sr_bn_finalize*
- * gained the twin buffers; 3: sr_conv_route, sr_comm_* / sr_allreduce_sum).  A binding must refuse a library whose version differs. */
-#define SR_ABI_VERSION 4
+ * gained the twin buffers; 3: sr_conv_route, sr_comm_* / sr_allreduce_sum; 4: sr_node_init_bwd's scratch; 5: sr_set_cu_share is per
+ * calling thread, SR_ROUTE_C3D128 names the channel-slice kernel, SR_ROUTE_C3D256, sr_conv_pair*).  A binding must refuse a library
+ * whose version differs. */
+#define SR_ABI_VERSION 5
 int sr_abi_version(void);
 
 /* Launches that follow FROM THE CALLING THREAD size their persistent grids (and everything derived from the CU count: tile shapes,
@@ -140,6 +142,36 @@ int sr_conv_route(const sr_conv_args* a, int dtype);
 /* rows of `stats` this exact launch writes (the stem runs on a direct-convolution kernel with its own partial layout; every
  * other launch follows sr_gemm_stats_tiles(M, Cout)).  Fill the geometry fields of `a`; pointers are not read. */
 int sr_conv_stats_rows(const sr_conv_args* a, int dtype);
+
+/* ---- A bottleneck's expansion conv FUSED with the NEXT block's reduce conv (train mode, bf16; torchvision chain
+ * conv3 -> bn3 -> (+identity) -> relu -> next.conv1, call site reference model.py:35):
+ *     z[M, Cexp] = relu( (relu(x*in_scale + in_shift) . w_exp[Cexp, Cmid]^T) * escale + eshift + res )      the block's output
+ *     y[M, Cmid] = z . w_red[Cmid, Cexp]^T                                                                   the next block's conv1, RAW
+ *     stats      = rows x [2][Cmid] partial column sums / sums of squares of y's fp32 accumulators (sr_bn_finalize consumes them)
+ * in one pass over z: the block output is written once and never read back by the reduce conv (per layer3 block 8.63 -> 6.17 GB of HBM
+ * traffic at batch 6144).  x: the RAW output of the bottleneck's 3x3 conv with in_scale / in_shift = its BatchNorm (both NULL: x is
+ * already normalised); escale / eshift: bn3's scale / shift (known before the launch: sr_bn_finalize_gram); res: the identity.
+ *   sr_conv_pair_supported   1 if sr_conv_pair serves (M, Cmid, Cexp, dtype): bf16, Cmid = 256, Cexp = 1024 (ResNet-50/101/152 layer3)
+ *   sr_conv_pair_pack_bytes  size of the packed weight stream
+ *   sr_conv_pair_pack        w_exp [Cexp][Cmid], w_red [Cmid][Cexp] (row-major, as sr_conv2d takes them) -> the stream the kernel's LDS
+ *                            ring consumes (MFMA fragments in phase order; once per weight version)
+ *   sr_conv_pair_stats_rows  rows of `stats` the launch writes (one per workgroup)
+ * z is bit-identical to sr_conv2d's weight-stationary expansion kernel and y to the generic kernel fed that z (same fp32 FMA and
+ * rounding points, same K order); the statistics differ from the unfused launch's in summation order only. */
+typedef struct sr_pair_args {
+  const void* x; const void* wpack; const void* res;
+  void* z; void* y;
+  const float* escale; const float* eshift;
+  const float* in_scale; const float* in_shift;
+  float* stats;
+  int64_t M;
+  int32_t Cmid, Cexp;
+} sr_pair_args;
+int sr_conv_pair_supported(int64_t M, int Cmid, int Cexp, int dtype);
+int sr_conv_pair_pack_bytes(int Cmid, int Cexp);
+int sr_conv_pair_pack(const void* w_exp, const void* w_red, void* out, int Cmid, int Cexp, int dtype, void* stream);
+int sr_conv_pair_stats_rows(int64_t M, int Cmid, int Cexp);
+int sr_conv_pair(const sr_pair_args* a, int dtype, void* stream);
 
 /* Stem + BatchNorm + ReLU + 3x3/2 max-pool in ONE launch: y[b,po,qo,c] = max over the 3x3/2 window (pad 1) of
  * relu(conv7x7/2(xp, w)[.,.,c] * scale[c] + shift[c]), xp / w as for sr_conv2d with stem != 0 (bf16, 64 output channels),

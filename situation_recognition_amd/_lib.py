@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SR_LIB_PATH") or os.path.join(_HERE, "libsrhip.so")   # SR_LIB_PATH: diagnostic builds only
 
-ABI_VERSION = 4                  # include/srhip.h: SR_ABI_VERSION
+ABI_VERSION = 5                  # include/srhip.h: SR_ABI_VERSION
 SR_F32, SR_BF16 = 0, 1
 ROUTE_WS, ROUTE_C3D, ROUTE_STEM, ROUTE_C3D128, ROUTE_C3D256 = 16, 18, 19, 20, 21     # sr_conv_route codes
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SIGMOID_MUL, ACT_TANH_BLEND = range(6)
@@ -44,6 +44,12 @@ class ConvArgs(C.Structure):
                 ("stats", C.c_void_p), ("escale", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p)]
 
 
+class PairArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("wpack", C.c_void_p), ("res", C.c_void_p), ("z", C.c_void_p), ("y", C.c_void_p),
+                ("escale", C.c_void_p), ("eshift", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
+                ("stats", C.c_void_p), ("M", C.c_int64), ("Cmid", C.c_int32), ("Cexp", C.c_int32)]
+
+
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 SIGNATURES = {
     "sr_abi_version": [],
@@ -56,6 +62,11 @@ SIGNATURES = {
     "sr_conv_stats_rows": [C.POINTER(ConvArgs), _I],
     "sr_conv_route": [C.POINTER(ConvArgs), _I],
     "sr_conv_in_affine_supported": [C.POINTER(ConvArgs), _I],
+    "sr_conv_pair_supported": [_L, _I, _I, _I],
+    "sr_conv_pair_pack_bytes": [_I, _I],
+    "sr_conv_pair_pack": [_P, _P, _P, _I, _I, _I, _P],
+    "sr_conv_pair_stats_rows": [_L, _I, _I],
+    "sr_conv_pair": [C.POINTER(PairArgs), _I, _P],
     "sr_stem_bn_relu_maxpool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sr_stem_prep": [_P, _P, _I, _I, _I, _I, _P],
     "sr_image_prep_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _P],

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libsrhip.so")
 OBJ = os.path.join(HERE, "_obj")
-SOURCES = ["gemm.hip", "gram.hip", "elementwise.hip", "ggnn.hip", "expand.hip", "fp8.hip", "stem.hip", "c3d.hip", "c3ds.hip", "comm.hip"]
+SOURCES = ["gemm.hip", "gram.hip", "elementwise.hip", "ggnn.hip", "expand.hip", "fp8.hip", "stem.hip", "c3d.hip", "c3ds.hip", "pair.hip", "comm.hip"]
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(PKG), "include", "srhip.h")]
 # -pragma-unroll-threshold: the GEMM epilogues are fully unrolled over 32 accumulator fragments; LLVM's default
 # threshold (16K) silently downgrades "#pragma unroll" to a partial unroll, which makes the accumulator index dynamic and

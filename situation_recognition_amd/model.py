@@ -152,6 +152,18 @@ class _ConvBN:
             self._cache[key] = hit
         return hit[1], hit[2]
 
+    def pair_pack(self, nxt, dtype):
+        """Weight stream of the fused launch `sr_conv_pair`: this unit (a bottleneck's expansion conv) followed by `nxt` (the next block's
+        reduce conv), both in MFMA-fragment order (ops.conv_pair_pack); rebuilt when either weight changes."""
+        key = ("pair", dtype)
+        sig = (self._sig(False), nxt._sig(False))
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                hit = (sig, ops.conv_pair_pack(self.raw(dtype)[0].view(self.cout_p, self.cin_p), nxt.raw(dtype)[0].view(nxt.cout_p, nxt.cin_p)))
+            self._cache[key] = hit
+        return hit[1]
+
     def fp8_eligible(self):
         """3x3 convolutions the e4m3 kernel serves (csrc/fp8.hip): 128 / 256 / 512 input channels, output channels a multiple of 128."""
         return self.k == 3 and self.pad == 1 and self.cin_p in (128, 256, 512) and self.cout_p % 128 == 0 and not self.stem
@@ -235,6 +247,7 @@ class resnet(nn.Module):
         self.gram_stats = True         # ... with launch 1 replaced by the input's Gram matrix for the expansion convs (bf16)
         self.fuse_stem_pool = True     # stem + BN + ReLU + maxpool as one kernel (bf16, 64-channel stem)
         self.lazy_bn2 = os.environ.get("SR_NO_LAZY_BN2") != "1"   # bn2 + ReLU applied by conv3 on load (train mode, bf16)
+        self.fuse_pairs = os.environ.get("SR_NO_PAIR") != "1"     # expansion conv + the next block's reduce conv in one launch (train, bf16)
         self.use_graphs = False        # eval-mode passes replayed from a captured hipGraph (opt-in: FCGGNN.enable_graphs())
         self.graph_train = False       # ... train-mode passes too (small per-GPU batches: ~900 launches of 10-200 us, 3 us apart)
         self._capturing = False
@@ -310,9 +323,20 @@ class resnet(nn.Module):
         return (then.k == 1 and then.stride == 1 and y.dtype == torch.bfloat16
                 and ops.conv_in_affine_supported(y, then.cout_p, 1, 1, 0, res=y, relu=True))
 
-    def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False, then=None, twin=None, quant_out=False):
+    def _pair_ok(self, u, nxt, n_pixels):
+        """Is expansion unit `u` followed by reduce unit `nxt` (the next block's conv1, fed this block's output and nothing else) served
+        by the fused launch `sr_conv_pair`?"""
+        return (self.fuse_pairs and nxt is not None and self.dtype == torch.bfloat16 and u.k == 1 and u.stride == 1 and nxt.k == 1
+                and nxt.stride == 1 and nxt.pad == 0 and nxt.cin_p == u.cout_p and nxt.cout_p == u.cin_p and n_pixels >= 128 * 256
+                and ops.conv_pair_supported(n_pixels, u.cin_p, u.cout_p, self.dtype))
+
+    def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False, then=None, twin=None, quant_out=False,
+              pre=None, fuse_next=None):
         """`then`: the unit that consumes this one's output next (lets BN-apply and the consumer's Gram pass share one sweep).
-        `twin` = (unit of a weight-identical backbone, its momentum): its running statistics are updated from the same batch."""
+        `twin` = (unit of a weight-identical backbone, its momentum): its running statistics are updated from the same batch.
+        `fuse_next`: the NEXT block's conv1 unit when this (expansion) unit may run fused with it (`sr_conv_pair`): the return value is
+        then (block output, (raw output of that conv1, its statistics partials)).  `pre` = such a pair, handed to that conv1 unit: its
+        convolution has already run."""
         dt = self.dtype
         f8_in = x.dtype == torch.uint8 and stem_hw is None         # e4m3 activations from the preceding unit (quant_out)
         if not train:
@@ -369,9 +393,18 @@ class resnet(nn.Module):
                 st = ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, stats_only=True)
                 scale, shift = ops.bn_finalize(st, x.shape[0] * Ho * Wo, gamma, beta, rm, rv, momentum, u.bn.eps, twin=tw)
             done()
+            if fuse_next is not None:
+                if res is not None and relu and self._pair_ok(u, fuse_next, x.shape[0] * Ho * Wo):
+                    # expansion conv + the next block's reduce conv in ONE pass over the block output: it is written once and not read
+                    # back by the reduce conv (reference chain conv3 -> bn3 -> add -> relu -> next.conv1, model.py:35)
+                    z, y1, st1 = ops.conv_pair(x, u.pair_pack(fuse_next, dt), res, scale, shift, in_affine=in_affine)
+                    return z, (y1, st1)
+                return ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=shift, escale=scale, res=res, relu=relu, in_affine=in_affine), None
             return ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=shift, escale=scale, res=res, relu=relu, in_affine=in_affine)
         lazy_in, self._lazy_in = self._lazy_in, None
-        if f8_in:
+        if pre is not None:                             # this convolution ran inside the previous block's fused launch
+            y, st = pre
+        elif f8_in:
             wq, dq = u.fp8_pack(self.fp8_act_scale)
             y, st = ops.conv3x3_fp8(x, wq, dq, u.cout_p, stride=u.stride, want_stats=True)
         else:
@@ -402,17 +435,33 @@ class resnet(nn.Module):
             return y
         return ops.bn_apply(y, scale, shift, res=res, relu=relu, out=y)
 
-    def _run_block(self, a, bi, train, momentum, tblock=None, T=lambda tu: None):
+    def _next_reduce(self, bi, train):
+        """The conv1 unit of block bi + 1 when it may run fused with block bi's expansion conv: train mode, a bottleneck whose only
+        reader of block bi's output besides the identity path is that 1x1 / stride-1 conv (no downsample branch), else None."""
+        blocks = self._plan()[1]
+        if not (train and self.fuse_pairs) or bi + 1 >= len(blocks):
+            return None
+        convs, ds = blocks[bi + 1]
+        return convs[0] if ds is None and len(convs) == 3 and len(blocks[bi][0]) == 3 else None
+
+    def _run_block(self, a, bi, train, momentum, tblock=None, T=lambda tu: None, pre=None, fuse_next=False):
         """One residual block on the NHWC activation `a` (torchvision Bottleneck / BasicBlock: conv-BN-ReLU chain, optional
-        1x1 downsample of the identity, add, ReLU).  `tblock`: the same block of a weight-identical twin backbone."""
+        1x1 downsample of the identity, add, ReLU).  `tblock`: the same block of a weight-identical twin backbone.
+        `pre`: (raw conv1 output, statistics) when the previous block's fused launch already ran this block's conv1.
+        `fuse_next`: try to run the NEXT block's conv1 inside this block's expansion launch; the return value is then (out, pre for
+        the next block or None)."""
         convs, ds = self._plan()[1][bi]
         tconvs, tds = tblock if tblock is not None else ([None] * len(convs), None)
         idn = a if ds is None else self._unit(a, ds, train, momentum, relu=False, twin=T(tds))
         y = a
         for i, u in enumerate(convs[:-1]):
             q8 = self.fp8 and len(convs) == 3 and i == 0 and convs[1].fp8_eligible()
-            y = self._unit(y, u, train, momentum, relu=True, then=convs[i + 1], twin=T(tconvs[i]), quant_out=q8)
-        return self._unit(y, convs[-1], train, momentum, relu=True, res=idn, twin=T(tconvs[-1]))
+            y = self._unit(y, u, train, momentum, relu=True, then=convs[i + 1], twin=T(tconvs[i]), quant_out=q8, pre=pre if i == 0 else None)
+        nxt = self._next_reduce(bi, train) if fuse_next else None
+        out = self._unit(y, convs[-1], train, momentum, relu=True, res=idn, twin=T(tconvs[-1]), fuse_next=nxt)
+        if not fuse_next:
+            return out
+        return out if isinstance(out, tuple) else (out, None)   # (a unit that does not take the two-launch route ignores fuse_next)
 
     def num_blocks(self):
         return len(self._plan()[1])
@@ -563,8 +612,9 @@ class resnet(nn.Module):
         with torch.no_grad():
             xp, H, W = prepped if prepped is not None else self.prepare_input(x)
             a = self._unit(xp, stem, train, momentum, relu=True, stem_hw=(H, W), pool_after=True, twin=T(tstem))
+            pre = None
             for bi in range(len(blocks)):
-                a = self._run_block(a, bi, train, momentum, tblocks[bi] if twin is not None else None, T)
+                a, pre = self._run_block(a, bi, train, momentum, tblocks[bi] if twin is not None else None, T, pre=pre, fuse_next=True)
             feat = ops.avgpool(a)
         if train and not self._capturing:
             self._stats_epoch += 1
