@@ -479,16 +479,19 @@ class resnet(nn.Module):
             self.model.bn1.num_batches_tracked += 1
         return a
 
-    def block_forward(self, a, bi):
+    def block_forward(self, a, bi, fuse_next=False, pre=None):
         """Residual block `bi` (0 .. num_blocks()-1, torchvision order layer1.0 ... layer4.2) alone, through exactly the launches
         the full pass makes for it: NHWC activation in the backbone's dtype -> NHWC activation.  Train mode updates that block's
-        running statistics once."""
+        running statistics once.
+        `fuse_next`: as the full train-mode pass does, run the NEXT block's conv1 inside this block's expansion launch where
+        `sr_conv_pair` serves the pair; returns (output, pre) with pre = (raw conv1 output of block bi + 1, its statistics partials)
+        or None.  `pre`: such a pair from block bi - 1: this block's conv1 has already run."""
         if not a.is_cuda or a.dtype != self.dtype or a.dim() != 4:
             raise SrError("block_forward expects an NHWC activation in the backbone's dtype on the GPU")
         m = self.model.bn1.momentum if self.model.bn1.momentum is not None else 0.1
         self._gram_stash = self._lazy_in = None
         with torch.no_grad():
-            out = self._run_block(a.contiguous(), bi, self.training, m)
+            out = self._run_block(a.contiguous(), bi, self.training, m, pre=pre, fuse_next=fuse_next)
         if self.training:
             self._stats_epoch += 1
             convs, ds = self._plan()[1][bi]

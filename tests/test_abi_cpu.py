@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound(libpath):
         assert hasattr(lib, name), name
     from situation_recognition_amd import _lib
     assert set(_lib.SIGNATURES) == declared
-    assert lib.sr_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.sr_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_argument_validation_needs_no_gpu(libpath):

@@ -240,3 +240,43 @@ def test_all_50_bottlenecks_train_mode_against_fp32_chain(world):
     finally:
         net.model.load_state_dict(keep)
         net.eval()
+
+
+def test_layer3_expansion_fused_with_the_next_reduce_conv(world):
+    """The train-mode pass runs every layer3 block's expansion conv FUSED with the next block's conv1 (`sr_conv_pair`, 35 pairs per
+    pass).  Every such pair on the oracle's block input (teacher forced, batch 1024 = 4 tiles per workgroup): the block output must be
+    BIT-IDENTICAL to the unfused launches' (which the test above holds to the fp32 chain), the raw conv1 output of the next block
+    bit-identical to the generic kernel fed that output, its statistics equal up to summation order, and the next block, continued
+    from the fused launch's tensors, bit-identical to the same block run from scratch on that output."""
+    net, acts, ops = world["net"], world["acts"], world["ops"]
+    keep = {k: v.clone() for k, v in net.model.state_dict().items()}
+    first3, n3 = 3 + 8, 36
+    fused = 0
+    try:
+        net.train()
+        for bi in range(first3, first3 + n3 - 1):
+            x = batch_from(nhwc(acts[bi][0]), 1024, 700 + bi)
+            y_ref = net.block_forward(x, bi)                                    # unfused launches
+            y, pre = net.block_forward(x, bi, fuse_next=True)
+            assert pre is not None, "block %d: the fused route was not taken" % bi
+            fused += 1
+            assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), bi
+            nxt = net._plan()[1][bi + 1][0][0]
+            w1 = nxt.raw(BF)[0]
+            y1_ref, st_ref = ops.conv2d(y_ref, w1, nxt.cout_p, 1, 1, 0, want_stats=True)
+            assert torch.equal(pre[0].view(torch.int16), y1_ref.view(torch.int16)), bi
+            s0, s1 = st_ref.double().sum(0), pre[1].double().sum(0)
+            assert float((s0 - s1).abs().max() / s0.abs().max()) < 1e-6, bi
+            if bi % 6 == 0:                                                     # the consumer side: block bi + 1 continued from `pre`
+                z_ref = net.block_forward(y_ref, bi + 1)
+                z = net.block_forward(y, bi + 1, pre=pre)
+                err = float((z.float() - z_ref.float()).abs().max())
+                assert err <= 2e-2 * float(z_ref.float().abs().max()), (bi, err)   # (scale / shift of bn1 from sums in another order)
+            del x, y, y_ref, pre
+        assert fused == n3 - 1
+        # layer3's last block feeds layer4.0 (a downsample branch reads its output too): not fused
+        x = batch_from(nhwc(acts[first3 + n3 - 1][0]), 1024, 799)
+        assert net.block_forward(x, first3 + n3 - 1, fuse_next=True)[1] is None
+    finally:
+        net.model.load_state_dict(keep)
+        net.eval()
