@@ -85,7 +85,9 @@ struct PairCfg {
   static constexpr int NA = YST;                         // tile start: X, loaded behind the last R phase, in front of Y's stores
   static_assert(EF == RF && EF % 4 == 0 && NPH % 4 == 0 && LDS <= 160 * 1024 && NE < 64 && NR < 64 && NI < 64 && NA < 64, "pair kernel budget");
 };
-typedef PairCfg<256, 3> PairL3;        // layer3: 256 -> 1024 -> 256 on 14 x 14 images
+typedef PairCfg<256, 3> PairL3;        // layer3: 256 -> 1024 -> 256 on 14 x 14 images (192-row tiles)
+typedef PairCfg<128, 4> PairL2;        // layer2: 128 ->  512 -> 128 on 28 x 28 images (256-row tiles; 128 + 64 accumulator registers)
+typedef PairCfg<64, 4> PairL1;         // layer1:  64 ->  256 ->  64 on 56 x 56 images
 
 constexpr int NB = 4;                   // weight fragments read ahead of their MFMAs
 
@@ -427,11 +429,34 @@ inline bool pair_enabled() {
   static const bool off = [] { const char* e = getenv("SR_NO_PAIR"); return e && e[0] == '1'; }();
   return !off;
 }
-inline bool pair_shape_ok(long M, int C, int CX) { return pair_enabled() && C == 256 && CX == 1024 && M >= 1 && M <= 0x7fffffffL; }
+inline bool pair_shape_ok(long M, int C, int CX) {
+  return pair_enabled() && (C == 256 || C == 128 || C == 64) && CX == 4 * C && M >= 1 && M <= 0x7fffffffL;
+}
 template <typename CF>
 inline unsigned pair_grid(long M) {
   const long ntiles = (M + CF::TM - 1) / CF::TM, cus = sr_num_cus();
   return (unsigned)(ntiles < cus ? ntiles : cus);
+}
+inline unsigned pair_grid_c(long M, int C) { return C == 256 ? pair_grid<PairL3>(M) : (C == 128 ? pair_grid<PairL2>(M) : pair_grid<PairL1>(M)); }
+
+template <typename CF>
+int pair_pack_launch(const void* w_exp, const void* w_red, void* out, hipStream_t st) {
+  const int n = CF::NPH * CF::EF * 64;
+  hipLaunchKernelGGL(pair_pack_kernel<CF>, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16_t*)w_exp, (const bf16_t*)w_red, (uint4*)out);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+template <typename CF, bool IN>
+int pair_launch_v(const PairArgs& s, unsigned grid, hipStream_t st) {
+  if (!sr_set_dynamic_lds_tagged<PairTag<CF, IN>>(reinterpret_cast<const void*>(&conv1x1_pair_kernel<CF, IN>), CF::LDS)) return SR_ERR_LAUNCH;
+  hipLaunchKernelGGL((conv1x1_pair_kernel<CF, IN>), dim3(grid), dim3(256), CF::LDS, st, s);
+  SR_CHECK_LAUNCH();
+  return SR_OK;
+}
+template <typename CF>
+int pair_launch(const PairArgs& s, hipStream_t st) {
+  const unsigned grid = pair_grid<CF>(s.M);
+  return s.in_scale ? pair_launch_v<CF, true>(s, grid, st) : pair_launch_v<CF, false>(s, grid, st);
 }
 
 }  // namespace
@@ -445,17 +470,16 @@ extern "C" int sr_conv_pair_pack_bytes(int Cmid, int Cexp) {
 }
 extern "C" int sr_conv_pair_stats_rows(int64_t M, int Cmid, int Cexp) {
   if (!pair_shape_ok(M, Cmid, Cexp)) return SR_ERR_UNSUPPORTED;
-  return (int)pair_grid<PairL3>(M);
+  return (int)pair_grid_c(M, Cmid);
 }
 extern "C" int sr_conv_pair_pack(const void* w_exp, const void* w_red, void* out, int Cmid, int Cexp, int dtype, void* stream) {
   if (!w_exp || !w_red || !out) return SR_ERR_ARG;
   if (dtype != SR_BF16) return SR_ERR_DTYPE;
   if (!pair_shape_ok(1, Cmid, Cexp)) return SR_ERR_UNSUPPORTED;
   if (((uintptr_t)w_exp | (uintptr_t)w_red | (uintptr_t)out) & 15) return SR_ERR_ARG;
-  const int n = PairL3::NPH * PairL3::EF * 64;
-  hipLaunchKernelGGL(pair_pack_kernel<PairL3>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_exp, (const bf16_t*)w_red, (uint4*)out);
-  SR_CHECK_LAUNCH();
-  return SR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  return Cmid == 256 ? pair_pack_launch<PairL3>(w_exp, w_red, out, st)
+                     : (Cmid == 128 ? pair_pack_launch<PairL2>(w_exp, w_red, out, st) : pair_pack_launch<PairL1>(w_exp, w_red, out, st));
 }
 extern "C" int sr_conv_pair(const sr_pair_args* a, int dtype, void* stream) {
   if (!a || !a->x || !a->wpack || !a->res || !a->z || !a->y || !a->escale || !a->eshift || !a->stats || a->M <= 0) return SR_ERR_ARG;
@@ -466,15 +490,6 @@ extern "C" int sr_conv_pair(const sr_pair_args* a, int dtype, void* stream) {
   PairArgs s;
   s.x = (const bf16_t*)a->x; s.wpack = (const bf16_t*)a->wpack; s.res = (const bf16_t*)a->res; s.z = (bf16_t*)a->z; s.y = (bf16_t*)a->y;
   s.escale = a->escale; s.eshift = a->eshift; s.in_scale = a->in_scale; s.in_shift = a->in_shift; s.stats = a->stats; s.M = a->M;
-  const unsigned grid = pair_grid<PairL3>(a->M);
   hipStream_t st = (hipStream_t)stream;
-  if (a->in_scale) {
-    if (!sr_set_dynamic_lds_tagged<PairTag<PairL3, true>>(reinterpret_cast<const void*>(&conv1x1_pair_kernel<PairL3, true>), PairL3::LDS)) return SR_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv1x1_pair_kernel<PairL3, true>), dim3(grid), dim3(256), PairL3::LDS, st, s);
-  } else {
-    if (!sr_set_dynamic_lds_tagged<PairTag<PairL3, false>>(reinterpret_cast<const void*>(&conv1x1_pair_kernel<PairL3, false>), PairL3::LDS)) return SR_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv1x1_pair_kernel<PairL3, false>), dim3(grid), dim3(256), PairL3::LDS, st, s);
-  }
-  SR_CHECK_LAUNCH();
-  return SR_OK;
+  return a->Cmid == 256 ? pair_launch<PairL3>(s, st) : (a->Cmid == 128 ? pair_launch<PairL2>(s, st) : pair_launch<PairL1>(s, st));
 }

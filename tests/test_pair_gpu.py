@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
-H, C, CX = 14, 256, 1024
+SHAPES = {"layer3": (14, 256), "layer2": (28, 128), "layer1": (56, 64)}     # (image side, mid channels); expansion = 4 x mid
 
 
 @pytest.fixture(scope="module")
@@ -21,7 +21,9 @@ def ops():
     return ops
 
 
-def operands(B, seed):
+def operands(B, seed, layer="layer3"):
+    H, C = SHAPES[layer]
+    CX = 4 * C
     g = torch.Generator(device="cuda").manual_seed(seed)
     x = torch.randn(B, H, H, C, device="cuda", generator=g).to(BF)                       # raw 3x3 output
     res = torch.relu(torch.randn(B, H, H, CX, device="cuda", generator=g)).to(BF)        # identity: a block output
@@ -33,6 +35,7 @@ def operands(B, seed):
 
 
 def fp32_reference(x, res, w3, w1, aff, esc, esh, rows):
+    C, CX = w1.shape
     M = x.numel() // C
     xa = x.view(M, C)[rows].float()
     if aff is not None:
@@ -41,19 +44,22 @@ def fp32_reference(x, res, w3, w1, aff, esc, esh, rows):
     return z
 
 
-@pytest.mark.parametrize("in_affine", [True, False])
-def test_pair_equals_the_two_launches_it_replaces(ops, in_affine):
-    """Batch 1024: 1046 tiles of 192 rows (the last one ragged: 64 rows, two waves of it empty) on 256 workgroups = 4 tiles each."""
-    B = 1024
-    x, res, w3, w1, aff, esc, esh = operands(B, 21)
+@pytest.mark.parametrize("layer,B,in_affine", [("layer3", 1024, True), ("layer3", 1024, False), ("layer2", 301, True), ("layer1", 75, True)])
+def test_pair_equals_the_two_launches_it_replaces(ops, layer, B, in_affine):
+    """Layer3 at batch 1024: 1046 tiles of 192 rows (the last one ragged: 64 rows, two waves of it empty) on 256 workgroups = 4 tiles
+    each; layer2 / layer1 (256-row tiles) at batches with as many rows and a ragged last tile."""
+    H, C = SHAPES[layer]
+    CX = 4 * C
+    x, res, w3, w1, aff, esc, esh = operands(B, 21, layer)
     M = B * H * H
-    assert M % 192 != 0 and (M + 191) // 192 >= 3 * 256
+    TM = 192 if layer == "layer3" else 256
+    assert M % TM != 0 and (M + TM - 1) // TM >= 3 * 256
     if not in_affine:
         x = torch.relu(x.float() * aff[0] + aff[1]).to(BF)
         aff = None
     from situation_recognition_amd import _lib
     assert ops.conv_route(B, H, H, C, CX, 1, 1, 0, res=True, relu=True, bias=True, escale=True, in_affine=in_affine) == _lib.ROUTE_WS
-    assert ops.conv_route(B, H, H, CX, C, 1, 1, 0, want_stats=True) == 4
+    assert ops.conv_route(B, H, H, CX, C, 1, 1, 0, want_stats=True) == ops.conv_route(6144, H, H, CX, C, 1, 1, 0, want_stats=True)
     z0 = ops.conv2d(x, w3, CX, 1, 1, 0, bias=esh, escale=esc, res=res, relu=True, in_affine=aff)
     y0, st0 = ops.conv2d(z0, w1, C, 1, 1, 0, want_stats=True)
     wp = ops.conv_pair_pack(w3, w1)
@@ -81,11 +87,14 @@ def test_pair_equals_the_two_launches_it_replaces(ops, in_affine):
         assert torch.equal(st1, st2)
 
 
-@pytest.mark.parametrize("B", [1, 3, 700])
-def test_pair_small_and_ragged_row_counts(ops, B):
-    """Fewer rows than one tile (196: one full tile + 4 rows), and a grid smaller than the chip; against the fp32 reference over all rows."""
-    x, res, w3, w1, aff, esc, esh = operands(B, 30 + B)
+@pytest.mark.parametrize("layer,B", [("layer3", 1), ("layer3", 3), ("layer3", 700), ("layer2", 1), ("layer2", 50), ("layer1", 1), ("layer1", 9)])
+def test_pair_small_and_ragged_row_counts(ops, layer, B):
+    """One tile and a few rows, grids smaller than the chip; against the fp32 reference over all rows."""
+    H, C = SHAPES[layer]
+    CX = 4 * C
+    x, res, w3, w1, aff, esc, esh = operands(B, 30 + B, layer)
     M = B * H * H
+    TM = 192 if layer == "layer3" else 256
     wp = ops.conv_pair_pack(w3, w1)
     z1, y1, st1 = ops.conv_pair(x, wp, res, esc, esh, in_affine=aff)
     rows = torch.arange(0, M, device="cuda")
@@ -94,7 +103,7 @@ def test_pair_small_and_ragged_row_counts(ops, B):
     yf = z1.view(M, CX).float() @ w1.float().t()
     assert float((yf - y1.view(M, C).float()).abs().max()) <= 1.2e-2 * float(yf.abs().max())
     s1 = st1.double().sum(0)
-    assert st1.shape[0] == min(256, (M + 191) // 192)
+    assert st1.shape[0] == min(256, (M + TM - 1) // TM)
     assert float((yf.double().sum(0) - s1[0]).abs().max() / s1[0].abs().max()) < 1e-5
     assert float(((yf.double() ** 2).sum(0) - s1[1]).abs().max() / s1[1].abs().max()) < 1e-5
 
@@ -102,7 +111,9 @@ def test_pair_small_and_ragged_row_counts(ops, B):
 def test_pair_rejects_what_it_does_not_serve(ops):
     from situation_recognition_amd import _lib
     assert ops.conv_pair_supported(200704, 256, 1024)
-    assert not ops.conv_pair_supported(200704, 128, 512) and not ops.conv_pair_supported(200704, 256, 1024, torch.float32)
+    assert ops.conv_pair_supported(200704, 128, 512) and ops.conv_pair_supported(200704, 64, 256)
+    assert not ops.conv_pair_supported(200704, 512, 2048) and not ops.conv_pair_supported(200704, 256, 512)
+    assert not ops.conv_pair_supported(200704, 256, 1024, torch.float32)
     x, res, w3, w1, aff, esc, esh = operands(2, 3)
     wp = ops.conv_pair_pack(w3, w1)
     with pytest.raises(_lib.SrError):

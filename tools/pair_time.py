@@ -1,7 +1,7 @@
 """The fused expansion -> next-block-reduce launch (sr_conv_pair, csrc/pair.hip) of layer3 against the two launches it replaces
 (weight-stationary expansion conv + generic reduce conv with statistics): bitwise comparison of both outputs, statistics against the
 unfused launch's and an fp64 reference on a row sample, then timing of both forms (alternating).
-usage: python tools/pair_time.py [batch] [check|time|both]"""
+usage: python tools/pair_time.py [batch] [check|time|both] [l3|l2|l1]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -9,7 +9,8 @@ from situation_recognition_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 6144
 mode = sys.argv[2] if len(sys.argv) > 2 else "both"
-H, C, CX = 14, 256, 1024
+H, C = {"l3": (14, 256), "l2": (28, 128), "l1": (56, 64)}[sys.argv[3] if len(sys.argv) > 3 else "l3"]
+CX = 4 * C
 dev, dt = "cuda", torch.bfloat16
 g = torch.Generator(device=dev).manual_seed(3)
 x = torch.randn(B, H, H, C, device=dev, generator=g).to(dt)                       # raw 3x3 output
@@ -52,7 +53,7 @@ if mode in ("check", "both"):
     print("z vs fp32 reference: max |diff| %.4g (range %.3g)" % ((zr - z1.view(M, CX)[idx].float()).abs().max().item(), zr.abs().max().item()))
     yr = z1.view(M, CX)[idx].float() @ w1.float().t()
     print("y vs fp32 reference (of the stored z): max |diff| %.4g (range %.3g)" % ((yr - y1.view(M, C)[idx].float()).abs().max().item(), yr.abs().max().item()))
-    yf = z1.view(M, CX).float() @ w1.float().t() if M <= 2000000 else None
+    yf = z1.view(M, CX).float() @ w1.float().t() if M * CX <= 2000000 * 1024 else None
     if yf is not None:
         print("statistics vs fp64 sums of the fp32 product: sum rel %.3g, sumsq rel %.3g" % (
             ((yf.double().sum(0) - s1[0]).abs().max() / s1[0].abs().max()).item(), (((yf.double() ** 2).sum(0) - s1[1]).abs().max() / s1[1].abs().max()).item()))
