@@ -337,8 +337,8 @@ def main():
                          alg_bytes_per_launch=round(bsum / n))
             return e
 
-        conv_tags = ["conv1x1", "conv3x3", "conv7x7", "conv3x3_fp8"]
-        head = entry(conv_tags, "mfma", "backbone convolutions, both passes, incl. statistics-only launches: conv_igemm_v3_kernel (reduce 1x1, downsample, stride-2 and layer4 3x3), conv3x3_c64_kernel / conv3x3_slices_kernel (layer1 / layer2 + layer3 stride-1 3x3, direct, BatchNorm of their input applied on load), conv1x1_ws_kernel (output-heavy 1x1), stem_conv_kernel + stem_pool_kernel (7x7 stem)")
+        conv_tags = ["conv1x1", "conv1x1_pair", "conv3x3", "conv7x7", "conv3x3_fp8"]
+        head = entry(conv_tags, "mfma", "backbone convolutions, both passes, incl. statistics-only launches: conv_igemm_v3_kernel (reduce 1x1, downsample, stride-2 and layer4 3x3), conv3x3_c64_kernel / conv3x3_slices_kernel (layer1 / layer2 + layer3 stride-1 3x3, direct, BatchNorm of their input applied on load), conv1x1_pair_kernel (expansion 1x1 fused with the next block's reduce 1x1, layers 1-3), conv1x1_ws_kernel (the other output-heavy 1x1), stem_conv_kernel + stem_pool_kernel (7x7 stem)")
         hbm_view = entry(conv_tags, "hbm", "backbone convolutions")
         # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately on this exact
         # command: profiles/conv_traffic.json records them with the gfx950 corrections); null for any other configuration
@@ -355,7 +355,8 @@ def main():
             pass
         by = [entry(["conv3x3"], "mfma", "3x3 convolutions: conv3x3_slices_kernel (layer3, layer2) + conv3x3_c64_kernel (layer1): direct, input BatchNorm on load; conv_igemm_v3_kernel (stride-2 layers, layer4)"),
               entry(["conv3x3_fp8"], "mfma", "conv3x3_fp8_kernel (e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4; peak = dense fp8)"), 
-              entry(["conv1x1"], "hbm", "1x1 convolutions: conv_igemm_v3_kernel (reduce, downsample) + conv1x1_ws_kernel (expansion + BN + residual + ReLU)"),
+              entry(["conv1x1_pair"], "hbm", "conv1x1_pair_kernel: a bottleneck's expansion conv (+ BN + residual + ReLU) fused with the next block's reduce conv (+ statistics), the block output written once and not read back; 44 pairs per backbone pass"),
+              entry(["conv1x1"], "hbm", "the other 1x1 convolutions: conv_igemm_v3_kernel (reduce convs of each layer's first block, downsample) + conv1x1_ws_kernel (expansion + BN + residual + ReLU of each layer's last block, layer4)"),
               entry(["conv7x7"], "mfma", "7x7 stem: stem_conv_kernel (statistics pass) + stem_pool_kernel (conv + BN + ReLU + max-pool); FLOPs counted once"),
               entry(["gram"], "hbm", "gram_kernel (Gram-matrix statistics of the expansion convs, fused with the preceding BN-apply)"),
               entry(["bn_apply"], "hbm", "bn_apply_kernel"), entry(["maxpool"], "hbm", "maxpool_kernel"),

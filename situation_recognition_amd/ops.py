@@ -230,7 +230,7 @@ def conv_pair(x, wpack, res, escale, eshift, in_affine=None):
     a.stats, a.M, a.Cmid, a.Cexp = stats.data_ptr(), M, Cmid, Cexp
     flops = 4.0 * M * Cmid * Cexp
     nbytes = 2.0 * (2 * M * Cmid + 2 * M * Cexp + 2 * Cmid * Cexp)     # x, res read; z, y written; both weight matrices once
-    check(_timed("conv1x1", flops, nbytes, lambda: lib().sr_conv_pair(C.byref(a), L.SR_BF16, stream())), "sr_conv_pair")
+    check(_timed("conv1x1_pair", flops, nbytes, lambda: lib().sr_conv_pair(C.byref(a), L.SR_BF16, stream())), "sr_conv_pair")
     return z, y, stats
 
 

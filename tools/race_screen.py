@@ -45,6 +45,8 @@ for B in (96, 768):
     bad += screen("B=%d 3x3 512->512 @7 + stats (generic 256x256 ping-pong kernel)" % (4 * B), lambda: ops.conv2d(x512, w512, 512, 3, 1, 1, want_stats=True))
     bad += screen("B=%d 1x1 256->1024 scale/shift/res/relu" % B, lambda: ops.conv2d(x256, w3, 1024, 1, 1, 0, bias=sh, escale=sc, res=x1024, relu=True))
     bad += screen("B=%d 1x1 1024->256 + stats" % B, lambda: ops.conv2d(x1024, w1, 256, 1, 1, 0, want_stats=True))
+    wp3 = ops.conv_pair_pack(w3, w1)
+    bad += screen("B=%d fused pair 256->1024->256 @14 (pair.hip)" % B, lambda: ops.conv_pair(x256, wp3, x1024, sc, sh, in_affine=(sc[:256].contiguous(), sh[:256].contiguous())))
     bad += screen("B=%d gram 256" % B, lambda: gm(ops.gram(x256.view(-1, 256)), 256))
     s2, h2 = torch.rand(256, device=dev) + .5, torch.randn(256, device=dev) * .1
     def fused():
@@ -59,6 +61,11 @@ for B in (96, 768):
     bad += screen("B=%d 3x3 128->128 @28 (direct kernel, c3ds.hip)" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True))
     bad += screen("B=%d 3x3 128->128 @28 direct, BN on load" % B, lambda: ops.conv2d(x128, w128, 128, 3, 1, 1, want_stats=True, in_affine=(s2[:128].contiguous(), h2[:128].contiguous())))
     bad += screen("B=%d 3x3 256->256 @14 direct, BN on load (c3ds.hip)" % B, lambda: ops.conv2d(x256, w33, 256, 3, 1, 1, want_stats=True, in_affine=(s2, h2)))
+    x512r, wp2 = t(B, 28, 28, 512), ops.conv_pair_pack(t(512, 128, scale=.08), t(128, 512, scale=.04))
+    bad += screen("B=%d fused pair 128->512->128 @28 (pair.hip)" % B, lambda: ops.conv_pair(x128, wp2, x512r, sc[:512].contiguous(), sh[:512].contiguous(), in_affine=(s2[:128].contiguous(), h2[:128].contiguous())))
+    x256r, wp1 = t(B, 56, 56, 256), ops.conv_pair_pack(t(256, 64, scale=.1), t(64, 256, scale=.06))
+    bad += screen("B=%d fused pair 64->256->64 @56 (pair.hip)" % B, lambda: ops.conv_pair(x64, wp1, x256r, sc[:256].contiguous(), sh[:256].contiguous(), in_affine=(s2[:64].contiguous(), h2[:64].contiguous())))
+    del x512r, x256r
     x128b = t(B, 24, 24, 128)
     bad += screen("B=%d 3x3 128->128 @24 (256x128 tiles)" % B, lambda: ops.conv2d(x128b, w128, 128, 3, 1, 1, want_stats=True))
     bad += screen("B=%d gram 128 / bn_gram 128" % B, lambda: (gm(ops.gram(x128.view(-1, 128)), 128), gm(ops.bn_gram(x128.view(-1, 128), s2[:128].contiguous(), h2[:128].contiguous()), 128)))
