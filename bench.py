@@ -122,8 +122,7 @@ def cpu_baseline(args):
         out["value_batch%d" % args.cpu_batch2] = round(rate2, 3)
         out["sample"] += "; value_batch%d: the same step at batch %d, 1 timed step after 1 warm-up (%.1f s)" % (args.cpu_batch2, args.cpu_batch2, dt2)
     else:
-        out["sample"] += ("; the second size of SURVEY 8(d), batch 256, is measured with --cpu-batch2 256 (profiles/r04/bench_b6144.json: "
-                          "4.4 images/sec on that box's 16 cores, where this sample gave 7.7-10.0)")
+        out["sample"] += "; the second size of SURVEY 8(d), batch 256, is measured in the same run with --cpu-batch2 256 (tools/collect_profiles.sh)"
     return out
 
 
@@ -176,6 +175,9 @@ def main():
     ap.add_argument("--cpu-batch2", type=int, default=0,
                     help="second CPU sample size (SURVEY 8d: 256; one timed step after one warm-up: 2 x 60 s on a 16-core box, so it is "
                          "off in the default run and on in tools/collect_profiles.sh, whose line is committed under profiles/)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
+                    help="gradient exchange of the N > 1 path: torch.distributed's all_reduce (RCCL under the nccl backend; the default) or "
+                         "the C ABI's sr_allreduce_sum (parallel.HipComm: RCCL bound by libsrhip itself, SURVEY 8b's export)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fp8", action="store_true",
@@ -217,7 +219,9 @@ def main():
     net.train()
     params = [p for p in net.parameters() if p.requires_grad]
     opt = torch.optim.Adamax(params, lr=0.002)
-    bucket = parallel.GradBucket(params) if world > 1 else None
+    comm = parallel.HipComm() if args.comm == "abi" else None     # (world 1: communicator and bucket plumbing run, nothing is exchanged)
+    bucket = parallel.GradBucket(params, comm=comm) if (world > 1 or comm is not None) else None
+    exch = []                                                     # per step: (event before, event after) bucket.finish() on the main stream
 
     lo, hi = parallel.shard_range(args.global_batch, rank, world)
     B = hi - lo
@@ -243,7 +247,11 @@ def main():
             # denominators; the gradient buckets are then summed over the ranks, launched from autograd hooks during backward
             loss = parallel.global_batch_loss(net, pv, pn, verb, nouns)[0]
             loss.backward()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             bucket.finish()
+            e1.record()
+            exch.append((e0, e1))
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
         return loss
@@ -267,6 +275,7 @@ def main():
         log("warm-up step %d/%d done" % (i + 1, args.warmup))
     parallel.barrier()
     torch.cuda.synchronize()
+    del exch[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -302,6 +311,15 @@ def main():
                                                 "ground_truth_branch": B * enc.get_max_role_count(), "of_full_form": B * enc.get_max_role_count()}),
                    "final_loss": round(final_loss, 4)},
     }
+    if bucket is not None:
+        # what the gradient exchange costs the step on the main stream: HIP events around bucket.finish() -- the launch of the
+        # buckets autograd's hooks had not sent yet plus the wait for all of them (the buckets launched during backward overlap it)
+        ex_ms = [a.elapsed_time(b) for a, b in exch]
+        out["config"]["gradient_exchange"] = {
+            "via": "sr_allreduce_sum (C ABI, RCCL bound by libsrhip: parallel.HipComm)" if comm is not None else
+                   "torch.distributed.all_reduce (%s backend)" % (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none"),
+            "buckets": len(bucket.buckets), "bytes": bucket.nbytes,
+            "exposed_ms_per_step": round(sum(ex_ms) / max(len(ex_ms), 1), 3)}
 
     if not args.no_roofline:                  # (every rank runs the profiled step -- it contains the collectives -- rank 0 reports it)
         # One extra training step, every libsrhip launch bracketed by HIP events on its launch stream (single stream: the

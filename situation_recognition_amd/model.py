@@ -685,6 +685,22 @@ class _GGNNFunction(torch.autograd.Function):
         # straight into the slices): a weight gradient is then ONE TN GEMM over all T * M rows -- dW_z = [dz_0; ..; dz_T-1]^T [n_0; ..;
         # n_T-1] -- instead of T launches of M rows each plus T partial reductions (round 4: at the 8-GPU share the verb path's M is
         # 768 rows, six K-steps per slice: 70 such launches per step cost 3 ms for almost no arithmetic).
+        if not any(ctx.needs_input_grad):
+            # evaluation / no_grad: nothing is kept for a backward -- two ping-pong state buffers and one set of per-step temporaries
+            # instead of 6-7 tensors of [T, M, D] (several GB at T = 8, 36 864 rows), and the result is a tensor of its own
+            hbuf = [h0, torch.empty_like(h0), torch.empty_like(h0)]
+            agg_b = None if verb else torch.empty_like(h0)
+            n_b, z_b, r_b, rh_b, c_b = (torch.empty_like(h0) for _ in range(5))
+            h = h0
+            for t in range(steps):
+                agg = h if verb else ops.aggregate(h, adj, idx, R, offs=offs, out=agg_b)
+                n = ops.gemm([(agg, g(Wp))], bias=bp, bias_scale=1.0 if verb else float(R), out=n_b)
+                z = ops.gemm([(n, g(Wz)), (h, g(Uz))], bias=bz, bias2=buz, act=ops.ACT_SIGMOID, out=z_b)
+                _, rh = ops.gemm([(n, g(Wr)), (h, g(Ur))], bias=br, bias2=bur, act=ops.ACT_SIGMOID_MUL, aux1=h, out=r_b, out2=rh_b)
+                nxt = hbuf[1 + (t & 1)]
+                ops.gemm([(n, g(Wh)), (rh, g(Uh))], bias=bh, bias2=buh, act=ops.ACT_TANH_BLEND, aux1=h, aux2=z, out=nxt, out2=c_b)
+                h = nxt
+            return h if steps > 0 else h0.clone()
         H = torch.empty((steps + 1, M, D), device=h0.device, dtype=dt)           # h_0 .. h_T
         H[0].copy_(h0)
         AGG = None if verb else torch.empty((steps, M, D), device=h0.device, dtype=dt)
@@ -699,6 +715,8 @@ class _GGNNFunction(torch.autograd.Function):
         ctx.meta = (R, verb, steps, shadow, adj, idx, offs)
         saved = (H, N_, Z, R_, RH, C_) + (() if verb else (AGG,))
         ctx.save_for_backward(*saved, *params)
+        # (a VIEW of the saved stack: it shares the stack's version counter, so the result must not be modified in place -- autograd
+        #  would refuse the backward; every caller in this package only reads it)
         return H[steps]
 
     @staticmethod

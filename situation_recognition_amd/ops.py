@@ -2,6 +2,7 @@
 allocates outputs with torch (device memory only) and enqueues the HIP kernel on the current stream.
 Nothing here computes on the CPU or with torch operators."""
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -94,10 +95,20 @@ def set_cu_share(share):
     return rc
 
 
+def _default_cu_share():
+    try:
+        v = int(os.environ.get("SR_CU_SHARE", "1"))          # (the library reads the same variable for its process default)
+    except ValueError:
+        v = 1
+    return v if 1 <= v <= 8 else 1
+
+
 def cu_share():
-    """The share this thread's launches are sized for (None = the library's default): part of the key of every captured hipGraph,
-    whose grids are baked in at capture time."""
-    return getattr(_CU_SHARE, "value", None)
+    """The share this thread's launches are sized for -- the EFFECTIVE value: a thread that never called set_cu_share and one that set
+    it back to the default report the same number.  Part of the key of every captured hipGraph, whose grids are baked in at capture
+    time (with None for "never set" the first overlapped forward changed the key of an identical configuration and every graph was
+    captured a second time, the old one kept alive with its static buffers)."""
+    return getattr(_CU_SHARE, "value", None) or _default_cu_share()
 
 
 def stats_tiles(M, N):

@@ -89,13 +89,16 @@ class HipComm:
         self._h = handle
         self.stream = torch.cuda.Stream()          # the collective's own stream: it runs beside the rest of the backward
 
-    def all_reduce_sum_(self, t, stream=None):
+    def all_reduce_sum_(self, t, stream=None, after=None):
         """In-place sum of the contiguous fp32 / bf16 CUDA tensor `t` over the ranks, ordered after the work already enqueued on
-        the current stream; returns an event the consumer waits on."""
+        the current stream (and after the event `after`, if given: the producer of `t` may have run on another stream); returns an
+        event the consumer waits on."""
         if not t.is_cuda or not t.is_contiguous():
             raise self._lib.SrError("all_reduce_sum_: contiguous CUDA tensor expected")
         s = stream or self.stream
         s.wait_stream(torch.cuda.current_stream())
+        if after is not None:
+            s.wait_event(after)
         self._lib.check(self._lib.lib().sr_allreduce_sum(self._h, t.data_ptr(), t.numel(), self._lib.dtype_code(t.dtype), s.cuda_stream),
                         "sr_allreduce_sum")
         t.record_stream(s)
@@ -168,6 +171,7 @@ class GradBucket:
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._pending = [len(b) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._done_ev = [None] * len(self.buckets)   # recorded on the stream of the hook that completed the bucket (CUDA only)
         self._next = 0                 # buckets [0, _next) have been launched: launches go out in bucket order on EVERY rank
         self.launch_order = []         # bucket indices in the order their collectives were issued since the last zero() (tests)
         self._works = []
@@ -199,6 +203,7 @@ class GradBucket:
                 p.grad = self.views[i]
         self._pending = [len(b) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._done_ev = [None] * len(self.buckets)
         self._next = 0
         self.launch_order = []
         self._works = []
@@ -211,10 +216,16 @@ class GradBucket:
         self._launched[b] = True
         self.launch_order.append(b)
         lo, hi = self._span(b)
+        # In-order launching means bucket b may go out from the hook of a parameter of ANOTHER bucket, on whatever stream that hook
+        # runs: the collective is ordered behind the event recorded when b's last gradient was accumulated (FCGGNN runs one noun
+        # branch's backward on a side stream), not only behind the launching hook's stream.
+        ev = self._done_ev[b]
         if self.comm is not None:
             if self.comm.world > 1:
-                self._works.append(_EventWork(self.comm.all_reduce_sum_(self.flat[lo:hi])))
+                self._works.append(_EventWork(self.comm.all_reduce_sum_(self.flat[lo:hi], after=ev)))
         elif _world(self.group) > 1:
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
             self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_grad(self, p):
@@ -228,6 +239,9 @@ class GradBucket:
             raise RuntimeError("GradBucket: a gradient arrived for a bucket whose all-reduce was already launched -- "
                                "call zero() before every backward (gradient accumulation over several backwards is not supported)")
         self._pending[b] -= 1
+        if self._pending[b] == 0 and self.flat.is_cuda:
+            self._done_ev[b] = torch.cuda.Event()
+            self._done_ev[b].record(torch.cuda.current_stream())
         # Rank-invariant launch order.  The order in which autograd completes the buckets depends on how the forward was BUILT, and
         # that can differ between ranks of one step (FCGGNN picks the packed-role / side-stream forms from its LOCAL batch, and
         # shard sizes differ by one): ranks issuing differently sized collectives in different orders hang RCCL or sum the wrong

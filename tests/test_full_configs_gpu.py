@@ -68,7 +68,7 @@ def _composed_pass_gate(net, ora, img, verb, lo8, s0, damp=0.2):
     instead of doubling it, so that a perturbation is carried, not amplified to O(1) (see ref_rounded's docstring for the numbers).
     Tolerance, derived on the spot: FLOOR = the distance between two rounding-matched oracle runs that differ only in the
     convolutions' summation precision (fp32 vs fp64) = what two CORRECT bf16-storage implementations differ by; the HIP pass must be
-    within 3 x FLOOR of the oracle.  And the gate must be able to see a wrong layer: ONE BatchNorm bias of the oracle shifted by 0.5
+    within 2 x FLOOR of the oracle (measured: 1.03-1.2 x; the wrong-layer probe lands at 6.4 x).  And the gate must be able to see a wrong layer: ONE BatchNorm bias of the oracle shifted by 0.5
     (layer3.17.bn1, one of 155) must land outside it.  HIP values come from batch-6144 / 1024-image runs (the benchmark's kernels)."""
     from oracle import ref_rounded
     from oracle.ref_resnet import calibrate_batchnorm_
@@ -96,16 +96,16 @@ def _composed_pass_gate(net, ora, img, verb, lo8, s0, damp=0.2):
     for got, m32, m64, name in ((fv, mfv, dfv, "verb"), (fn, mfn, dfn, "noun")):
         floor, err = rel(m32, m64), rel(got, m32)
         print("GATED config3 (damped net) pooled %s features vs rounding-matched oracle: relative L2 %.5f; floor (fp32 vs fp64 summation) %.5f; "
-              "gate 3 x floor = %.5f" % (name, err, floor, 3 * floor))
-        assert err < 3 * floor, (name, err, floor)
+              "gate 2 x floor = %.5f" % (name, err, floor, 2 * floor))
+        assert err < 2 * floor, (name, err, floor)
     print("REPORTED config3 (damped net) pooled verb features vs pure fp32 oracle: relative L2 %.5f" % rel(fv, pure_fv))
     # logits (verb branch, ground-truth-verb noun branch)
     for got, m32, m64, w, name in ((full[0], mv, dv, pure[0], "verb"), (full[2], mg, dg, pure[2], "gt_nouns")):
         got = got[lo8:lo8 + 8].float().cpu()
         floor, err, rng = float((m32 - m64).abs().max()), float((got - m32).abs().max()), float(w.abs().max())
         print("GATED config3 (damped net) %s logits vs rounding-matched oracle: max abs err %.5f; floor %.5f; gate %.5f; logit range %.3f; "
-              "vs pure fp32 oracle %.5f" % (name, err, floor, 3 * floor, rng, float((got - w).abs().max())))
-        assert err < 3 * floor, (name, err, floor)
+              "vs pure fp32 oracle %.5f" % (name, err, floor, 2 * floor, rng, float((got - w).abs().max())))
+        assert err < 2 * floor, (name, err, floor)
     # the gate sees a wrong layer: one BatchNorm bias of 155 off by 0.5
     blk = ora.convnet_verbs.model.layer3[17]
     with torch.no_grad():
@@ -114,7 +114,7 @@ def _composed_pass_gate(net, ora, img, verb, lo8, s0, damp=0.2):
         blk.bn1.bias.sub_(0.5)
     moved = rel(bad, mfv)
     print("config3 (damped net): one BatchNorm bias (layer3.17.bn1) shifted by 0.5 moves the pooled features by %.5f" % moved)
-    assert moved > 3 * rel(mfv, dfv), "the gate could not see a wrong layer"
+    assert moved > 2 * rel(mfv, dfv), "the gate could not see a wrong layer"
 
 
 def _device_images(B, seed):

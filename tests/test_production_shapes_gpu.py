@@ -68,7 +68,7 @@ B14 = 1024                                            # 1024 x 14 x 14 = 200 704
 
 def test_conv3x3_generic_statistics_kernel(ops):
     """The 3x3 the GENERIC implicit-GEMM kernel still carries in the benchmark: layer4's 512 -> 512 @7 (2 launches per pass; layer1-3's
-    stride-1 3x3s have direct kernels since rounds 2-4, c3d*.hip) -- `<bf16,bf16,4,7>` (one-pass raw + statistics epilogue): raw bf16
+    stride-1 3x3s have direct kernels since rounds 2-4: c3d.hip, c3ds.hip) -- `<bf16,bf16,4,7>` (one-pass raw + statistics epilogue): raw bf16
     output + running BatchNorm partial sums over 3 tiles per workgroup; padding taps through out-of-range buffer loads.  Then the
     GENERAL statistics kernel `<bf16,bf16,4,1>` (statistics of conv + bias, masked edge path) on the same operands."""
     from situation_recognition_amd import _lib
@@ -482,9 +482,9 @@ def test_conv3x3_128_128_direct_kernel(ops, B):
 
 @pytest.mark.parametrize("B", [2, 37, 600])
 def test_direct_128_3x3_normalises_its_input_on_load(ops, B):
-    """bn1 -> relu -> conv2 of a layer2 bottleneck without the normalised tensor: the 128-channel direct kernel applies scale / shift +
-    ReLU to the NEXT tile's patch in LDS while the current tile multiplies (pad pixels and the rows above / below the image stay
-    zero: the convolution pads the NORMALISED tensor).  Output and BatchNorm partial sums bit-identical to the same kernel on the
+    """bn1 -> relu -> conv2 of a layer2 bottleneck without the normalised tensor: the channel-slice kernel (c3ds.hip, 14-row tiles) applies
+    scale / shift + ReLU to the NEXT 32-channel slice of the patch in LDS while the current slice multiplies (pad pixels and the rows
+    above / below the image stay zero: the convolution pads the NORMALISED tensor).  Output and BatchNorm partial sums bit-identical to the same kernel on the
     tensor bn_apply wrote, and within bf16 rounding of the fp32 reference."""
     Cc, H = 128, 28
     y1 = rnd(B, H, H, Cc, seed=B + 3)
@@ -512,10 +512,13 @@ def test_direct_128_3x3_normalises_its_input_on_load(ops, B):
     close(lazy.view(-1, Cc), ref.reshape(-1, Cc))
     # the positions the in-LDS normalisation can get wrong and a max-over-the-tensor tolerance would average away: image corners and
     # edges (patch row 0 / the row below the image / the pad columns must be ZERO after the transform, not relu(shift)), and the rows
-    # where one tile ends and the next begins (4-row tiles: 3|4, 7|8, ...), each against the fp32 reference at the tensor's tolerance
+    # where one tile ends and the next begins (the channel-slice kernel's tiles are 14 image rows: rows 13 | 14 of a 28-row image are the
+    # one seam, the place where the patch row above / below a tile is a real image row and not a pad), each against the fp32 reference
+    # at the tensor's tolerance
     edge = torch.zeros(H, H, dtype=torch.bool, device="cuda")
     edge[0], edge[-1], edge[:, 0], edge[:, -1] = True, True, True, True
-    edge[3::4], edge[4::4] = True, True
+    for seam in range(14, H, 14):
+        edge[seam - 1], edge[seam] = True, True
     close(lazy[:, edge], ref[:, edge], k=float(ref.abs().max() / ref[:, edge].abs().max()))
     corners = lazy[:, [0, 0, -1, -1], [0, -1, 0, -1]].float()
     wrong_pad = F.conv2d(F.pad(F.relu(y1.float() * sc + sh).to(BF).float().permute(0, 3, 1, 2), (1, 1, 1, 1), value=0.0)
