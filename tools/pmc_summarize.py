@@ -16,7 +16,7 @@ with open(os.path.join(out, "bench_%s_kernel_stats.csv" % tag), "w") as f:
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
     for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         w.writerow([k, n, t, "%.1f" % (t / n), "%.2f" % (100.0 * t / tot)])
-CONV = ("conv_igemm", "conv1x1_expand", "conv1x1_ws", "stem_conv_kernel", "stem_pool_kernel", "conv3x3_fp8", "conv3x3_c64", "conv3x3_c128", "conv3x3_c256", "conv3x3_slices")   # the backbone convolution kernels
+CONV = ("conv_igemm", "conv1x1_expand", "conv1x1_ws", "conv1x1_pair", "stem_conv_kernel", "stem_pool_kernel", "conv3x3_fp8", "conv3x3_c64", "conv3x3_c128", "conv3x3_c256", "conv3x3_slices")   # the backbone convolution kernels
 conv = {k: v for k, v in agg.items() if any(c in k for c in CONV)}
 n_conv, t_conv = sum(v[0] for v in conv.values()), sum(v[1] for v in conv.values())
 
@@ -47,7 +47,7 @@ by_kernel(write, "WRITE_SIZE")
 fs, fn = counter_sum(fetch, "FETCH_SIZE")
 ws, wn = counter_sum(write, "WRITE_SIZE")
 res = {
-    "kernel": "backbone convolutions: conv_igemm_* + conv1x1_ws_kernel + conv3x3_c64_kernel + conv3x3_slices_kernel + stem_conv/stem_pool_kernel (all variants)",
+    "kernel": "backbone convolutions: conv_igemm_* + conv1x1_pair_kernel + conv1x1_ws_kernel + conv3x3_c64_kernel + conv3x3_slices_kernel + stem_conv/stem_pool_kernel (all variants)",
     "launches_in_trace": n_conv, "avg_launch_us_in_trace": t_conv / n_conv / 1e3,
     "fetch_size_kib_sum": fs, "fetch_launches": fn, "write_size_kib_sum": ws, "write_launches": wn,
     "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), WRITE_SIZE exact; separate --pmc passes",
