@@ -81,7 +81,7 @@ inline int sr_num_cus() {
 // relu(x * scale + shift) on the eight bf16 values of a 16-byte chunk, rounded back to bf16.  `sp` / `hp`: the chunk's eight scales /
 // shifts in PAIR ORDER -- channels [0, 2, 1, 3, 4, 6, 5, 7] (sr_pair_order) -- as two 16-byte vectors each, so that the packed f32
 // operations (two channels per instruction: the low halves of two adjacent words, then their high halves) take their operands from
-// adjacent registers as loaded, and v_cvt_pk_bf16_f32 puts (low, high) straight back into one word: 24 vector instructions per
+// adjacent registers as loaded, and v_cvt_pk_bf16_f32 puts (low, high) straight back into one word: 20 vector instructions per
 // chunk (the scalar form compiled to ~60, half of them register moves).
 typedef float sr_f32x2 __attribute__((ext_vector_type(2)));
 typedef float sr_f32x4 __attribute__((ext_vector_type(4)));
@@ -98,11 +98,15 @@ __device__ __forceinline__ sr_u32x4 sr_affine_relu_chunk(sr_u32x4 v, sr_f32x4 s0
     sr_f32x2 hi = {__uint_as_float(v[2 * p] & 0xffff0000u), __uint_as_float(v[2 * p + 1] & 0xffff0000u)};
     lo = __builtin_elementwise_fma(lo, sr_f32x2{s[0], s[1]}, sr_f32x2{h[0], h[1]});
     hi = __builtin_elementwise_fma(hi, sr_f32x2{s[2], s[3]}, sr_f32x2{h[2], h[3]});
-    lo = __builtin_elementwise_max(lo, sr_f32x2{0.f, 0.f});
-    hi = __builtin_elementwise_max(hi, sr_f32x2{0.f, 0.f});
+    // ReLU AFTER the rounding, on the packed pair: a negative bf16 (including -0) is a negative int16, so max(., 0) as int16 is the
+    // ReLU -- rounding is monotonic and keeps the sign, so round(relu(x)) == relu(round(x)) bit for bit (round 5: 20 vector
+    // instructions per chunk instead of 24; every consumer that normalises on load and the Gram sweep share this one function)
     const sr_bf16x2 w0 = __builtin_convertvector(sr_f32x2{lo[0], hi[0]}, sr_bf16x2), w1 = __builtin_convertvector(sr_f32x2{lo[1], hi[1]}, sr_bf16x2);
-    o[2 * p] = __builtin_bit_cast(unsigned, w0);
-    o[2 * p + 1] = __builtin_bit_cast(unsigned, w1);
+    unsigned u0 = __builtin_bit_cast(unsigned, w0), u1 = __builtin_bit_cast(unsigned, w1);
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(u0) : "v"(u0));
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(u1) : "v"(u1));
+    o[2 * p] = u0;
+    o[2 * p + 1] = u1;
   }
   return o;
 }
