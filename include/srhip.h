@@ -146,14 +146,16 @@ int sr_conv_stats_rows(const sr_conv_args* a, int dtype);
 /* ---- A bottleneck's expansion conv FUSED with the NEXT block's reduce conv (train mode, bf16; torchvision chain
  * conv3 -> bn3 -> (+identity) -> relu -> next.conv1, call site reference model.py:35):
  *     z[M, Cexp] = relu( (relu(x*in_scale + in_shift) . w_exp[Cexp, Cmid]^T) * escale + eshift + res )      the block's output
- *     y[M, Cmid] = z . w_red[Cmid, Cexp]^T                                                                   the next block's conv1, RAW
- *     stats      = rows x [2][Cmid] partial column sums / sums of squares of y's fp32 accumulators (sr_bn_finalize consumes them)
+ *     y[M, Cred] = z . w_red[Cred, Cexp]^T                                                                   the next block's conv1, RAW
+ *     stats      = rows x [2][Cred] partial column sums / sums of squares of y's fp32 accumulators (sr_bn_finalize consumes them)
  * in one pass over z: the block output is written once and never read back by the reduce conv (per layer3 block 8.63 -> 6.17 GB of HBM
  * traffic at batch 6144).  x: the RAW output of the bottleneck's 3x3 conv with in_scale / in_shift = its BatchNorm (both NULL: x is
  * already normalised); escale / eshift: bn3's scale / shift (known before the launch: sr_bn_finalize_gram); res: the identity.
- *   sr_conv_pair_supported   1 if sr_conv_pair serves (M, Cmid, Cexp, dtype): bf16, Cmid = 256, Cexp = 1024 (ResNet-50/101/152 layer3)
+ *   sr_conv_pair_supported   1 if sr_conv_pair serves (M, Cmid, Cexp, Cred, dtype): bf16, Cexp = 4 Cmid, and Cred = Cmid in {256, 128, 64} (the
+ *                            next block lies in the same layer: ResNet-50/101/152 layers 3 / 2 / 1) or Cred = 2 Cmid, Cmid in {128, 64} (the next
+ *                            block opens the next layer: its conv1 is 1x1 / stride 1 on the block output as well)
  *   sr_conv_pair_pack_bytes  size of the packed weight stream
- *   sr_conv_pair_pack        w_exp [Cexp][Cmid], w_red [Cmid][Cexp] (row-major, as sr_conv2d takes them) -> the stream the kernel's LDS
+ *   sr_conv_pair_pack        w_exp [Cexp][Cmid], w_red [Cred][Cexp] (row-major, as sr_conv2d takes them) -> the stream the kernel's LDS
  *                            ring consumes (MFMA fragments in phase order; once per weight version)
  *   sr_conv_pair_stats_rows  rows of `stats` the launch writes (one per workgroup)
  * z is bit-identical to sr_conv2d's weight-stationary expansion kernel and y to the generic kernel fed that z (same fp32 FMA and
@@ -166,11 +168,12 @@ typedef struct sr_pair_args {
   float* stats;
   int64_t M;
   int32_t Cmid, Cexp;
+  int32_t Cred, _pad;      /* output channels of the reduce conv (0 = Cmid) */
 } sr_pair_args;
-int sr_conv_pair_supported(int64_t M, int Cmid, int Cexp, int dtype);
-int sr_conv_pair_pack_bytes(int Cmid, int Cexp);
-int sr_conv_pair_pack(const void* w_exp, const void* w_red, void* out, int Cmid, int Cexp, int dtype, void* stream);
-int sr_conv_pair_stats_rows(int64_t M, int Cmid, int Cexp);
+int sr_conv_pair_supported(int64_t M, int Cmid, int Cexp, int Cred, int dtype);
+int sr_conv_pair_pack_bytes(int Cmid, int Cexp, int Cred);
+int sr_conv_pair_pack(const void* w_exp, const void* w_red, void* out, int Cmid, int Cexp, int Cred, int dtype, void* stream);
+int sr_conv_pair_stats_rows(int64_t M, int Cmid, int Cexp, int Cred);
 int sr_conv_pair(const sr_pair_args* a, int dtype, void* stream);
 
 /* Stem + BatchNorm + ReLU + 3x3/2 max-pool in ONE launch: y[b,po,qo,c] = max over the 3x3/2 window (pad 1) of

@@ -47,7 +47,7 @@ class ConvArgs(C.Structure):
 class PairArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("wpack", C.c_void_p), ("res", C.c_void_p), ("z", C.c_void_p), ("y", C.c_void_p),
                 ("escale", C.c_void_p), ("eshift", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
-                ("stats", C.c_void_p), ("M", C.c_int64), ("Cmid", C.c_int32), ("Cexp", C.c_int32)]
+                ("stats", C.c_void_p), ("M", C.c_int64), ("Cmid", C.c_int32), ("Cexp", C.c_int32), ("Cred", C.c_int32), ("_pad", C.c_int32)]
 
 
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
@@ -62,10 +62,10 @@ SIGNATURES = {
     "sr_conv_stats_rows": [C.POINTER(ConvArgs), _I],
     "sr_conv_route": [C.POINTER(ConvArgs), _I],
     "sr_conv_in_affine_supported": [C.POINTER(ConvArgs), _I],
-    "sr_conv_pair_supported": [_L, _I, _I, _I],
-    "sr_conv_pair_pack_bytes": [_I, _I],
-    "sr_conv_pair_pack": [_P, _P, _P, _I, _I, _I, _P],
-    "sr_conv_pair_stats_rows": [_L, _I, _I],
+    "sr_conv_pair_supported": [_L, _I, _I, _I, _I],
+    "sr_conv_pair_pack_bytes": [_I, _I, _I],
+    "sr_conv_pair_pack": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "sr_conv_pair_stats_rows": [_L, _I, _I, _I],
     "sr_conv_pair": [C.POINTER(PairArgs), _I, _P],
     "sr_stem_bn_relu_maxpool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sr_stem_prep": [_P, _P, _I, _I, _I, _I, _P],

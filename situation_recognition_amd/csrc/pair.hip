@@ -60,34 +60,39 @@ struct PairArgs {
   long M;
 };
 
-// C mid channels (K of the expansion, N of the reduce conv), RW row fragments per wave
-template <int C_, int RW_>
+// C mid channels (K of the expansion), RW row fragments per wave, CR output channels of the reduce conv: C inside a layer, 2 C where the
+// next block opens the next layer (its conv1 is 1x1 / stride 1 on the block output too, torchvision v1.5)
+template <int C_, int RW_, int CR_ = C_>
 struct PairCfg {
-  static constexpr int C = C_, CX = 4 * C_, RW = RW_;
+  static constexpr int C = C_, CX = 4 * C_, RW = RW_, CR = CR_;
   static constexpr int TM = 4 * RW * 16;                 // rows per tile
   static constexpr int NCH = CX / 64;                    // chunks of 64 Z columns
   static constexpr int KT = C / 32;                      // K-steps of the expansion
-  static constexpr int QF = C / 16;                      // column fragments of Y
+  static constexpr int QF = CR / 16;                     // column fragments of Y
   static constexpr int EF = KT * 4, RF = 2 * QF;         // weight fragments per E / R phase
-  static constexpr int HALF = EF * 1024;                 // bytes per phase = ring slot
-  static constexpr int PW = EF / 4;                      // LDS-DMA pieces per wave and phase
-  static constexpr int NPH = 2 * NCH;                    // phases per tile = length of the weight stream in slots
+  static constexpr int HALF = (EF > RF ? EF : RF) * 1024;   // a ring slot holds one phase's fragments (the larger of the two kinds)
+  static constexpr int PWE = EF / 4, PWR = RF / 4;       // LDS-DMA pieces per wave of an E / R phase
+  static constexpr int CHB = (EF + RF) * 1024;           // bytes of the weight stream per chunk: E phase, then R phase
   // LDS: the small tables FIRST (their reads then are one per-lane base register + an immediate offset: behind the 128 KiB ring the
   // offsets do not fit the instruction's 16 bits and hipcc keeps one address register per table access alive across the tile loop)
-  static constexpr int TAB = 0, INAFF = TAB + 2 * CX * 4, STAT = INAFF + 2 * C * 4, RING = STAT + 4 * 2 * C * 4, LDS = RING + 4 * HALF;
+  static constexpr int TAB = 0, INAFF = TAB + 2 * CX * 4, STAT = INAFF + 2 * C * 4, RING = STAT + 4 * 2 * CR * 4, LDS = RING + 4 * HALF;
   static constexpr int ST = 2 * RW, LD = 2 * RW;         // Z stores / identity loads per chunk and wave
-  static constexpr int YST = RW * (C / 32);              // Y stores per tile and wave
+  static constexpr int YST = RW * (CR / 32);             // Y stores per tile and wave
   // vector-memory operations a wave has issued BEHIND the one it waits for (steady state; at a tile boundary there are more -- the next
-  // tile's X loads, Y's stores -- and a smaller count only waits for more than it must):
-  static constexpr int NE = PW + ST + LD + PW;           // E phase start: the pieces of this phase, issued at the start of R two chunks ago
-  static constexpr int NR = ST + LD + PW + PW + ST + LD; // R phase start: the pieces issued at the start of the previous chunk's E phase
-  static constexpr int NI = 4 * PW + ST + LD;            // epilogue: the identity loads issued in the epilogue two chunks ago
+  // tile's X loads, Y's stores -- and a smaller count only waits for more than it must).  The pieces of phase p + 3 go out during phase
+  // p: an E phase issues the PWR pieces of an R phase, an R phase the PWE pieces of an E phase; the epilogue between them ST + LD.
+  static constexpr int NE = PWR + ST + LD + PWE;         // E(c) start: its pieces went out during R(c - 2); E(c - 1), its epilogue, R(c - 1) since
+  static constexpr int NR = ST + LD + PWE + PWR + ST + LD; // R(c) start: its pieces went out during E(c - 1); epilogue, R(c - 1), E(c), epilogue since
+  static constexpr int NI = 2 * PWE + 2 * PWR + ST + LD; // epilogue: the identity loads issued at the end of the epilogue two chunks ago
   static constexpr int NA = YST;                         // tile start: X, loaded behind the last R phase, in front of Y's stores
-  static_assert(EF == RF && EF % 4 == 0 && NPH % 4 == 0 && LDS <= 160 * 1024 && NE < 64 && NR < 64 && NI < 64 && NA < 64, "pair kernel budget");
+  static_assert(EF % 4 == 0 && RF % 4 == 0 && NCH % 2 == 0 && EF % PWR == 0 && RF % PWE == 0 && LDS <= 160 * 1024 && NE < 64 && NR < 64 && NI < 64 && NA < 64,
+                "pair kernel budget");
 };
 typedef PairCfg<256, 3> PairL3;        // layer3: 256 -> 1024 -> 256 on 14 x 14 images (192-row tiles)
 typedef PairCfg<128, 4> PairL2;        // layer2: 128 ->  512 -> 128 on 28 x 28 images (256-row tiles; 128 + 64 accumulator registers)
 typedef PairCfg<64, 4> PairL1;         // layer1:  64 ->  256 ->  64 on 56 x 56 images
+typedef PairCfg<128, 3, 256> PairL23;  // layer2's last block -> layer3.0.conv1: 128 -> 512 -> 256 on 28 x 28 images
+typedef PairCfg<64, 4, 128> PairL12;   // layer1's last block -> layer2.0.conv1:  64 -> 256 -> 128 on 56 x 56 images
 
 constexpr int NB = 4;                   // weight fragments read ahead of their MFMAs
 
@@ -139,7 +144,7 @@ __host__ __device__ constexpr int pair_sigma(int j, int m) { return 32 * (j >> 1
 
 template <typename CF, bool IN>
 __device__ __forceinline__ void pair_body(const PairArgs& p) {
-  constexpr int C = CF::C, CX = CF::CX, RW = CF::RW, TM = CF::TM, NCH = CF::NCH, KT = CF::KT, QF = CF::QF, HALF = CF::HALF, PW = CF::PW;
+  constexpr int C = CF::C, CX = CF::CX, CR = CF::CR, RW = CF::RW, TM = CF::TM, NCH = CF::NCH, KT = CF::KT, QF = CF::QF, HALF = CF::HALF, PWE = CF::PWE, PWR = CF::PWR;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // escale, eshift | in-affine | 4 statistics rows | weight ring
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -149,7 +154,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
 
   float* const tab = reinterpret_cast<float*>(smem + CF::TAB);
   float* const inaff = reinterpret_cast<float*>(smem + CF::INAFF);
-  float* const lstat = reinterpret_cast<float*>(smem + CF::STAT) + wave * (2 * C);
+  float* const lstat = reinterpret_cast<float*>(smem + CF::STAT) + wave * (2 * CR);
   for (int k = threadIdx.x; k < CX; k += 256) { tab[k] = p.escale[k]; tab[CX + k] = p.eshift[k]; }
   if (IN) {
     for (int k = threadIdx.x; k < C; k += 256) {          // (pair order inside every 8-channel chunk: sr_affine_relu_chunk)
@@ -157,19 +162,27 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
       inaff[k] = p.in_scale[ch]; inaff[C + k] = p.in_shift[ch];
     }
   }
-  for (int k = lane; k < 2 * C; k += 64) lstat[k] = 0.f;
+  for (int k = lane; k < 2 * CR; k += 64) lstat[k] = 0.f;
 
-  // ---- weight stream: phase ph (0 .. NPH-1, cyclic) = HALF bytes; wave w copies pieces w PW .. w PW + PW - 1 of every phase
-  const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpack, 0, CF::NPH * HALF, 0x00020000);
-  const int w_vo = wave * (PW * 1024) + lane * 16;
-  auto issue_w1 = [&](int slot, int ph, int i) {           // slot, i: compile time at every call site; ph: scalar
+  // ---- weight stream: per chunk EF + RF fragments of 1 KiB (E phase, then R phase), cyclic over the NCH chunks of a tile; of a phase
+  // with NP pieces per wave, wave w copies pieces w NP .. w NP + NP - 1
+  const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpack, 0, NCH * CF::CHB, 0x00020000);
+  const int w_lane = lane * 16;
+  // piece i of the E phase (KIND 0) / R phase (KIND 1) of chunk c (0 .. NCH-1) into ring slot `slot` (slot, kind, i: compile time at every call site)
+  auto issue_w1 = [&](int slot, int kind, int c, int i) {
     if (PAIR_ABL & 4) return;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (__attribute__((address_space(3))) void*)(smem + CF::RING + slot * HALF + (wave * PW + i) * 1024), 16, w_vo,
-                                             ph * HALF + i * 1024, 0, 0);
+    const int np = kind ? PWR : PWE;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (__attribute__((address_space(3))) void*)(smem + CF::RING + slot * HALF + (wave * np + i) * 1024), 16, w_lane,
+                                             c * CF::CHB + (kind ? CF::EF * 1024 : 0) + (wave * np + i) * 1024, 0, 0);
   };
-  auto issue_w = [&](int slot, int ph) {
+  auto issue_w = [&](int slot, int kind, int c) {
+    if (kind) {
 #pragma unroll
-    for (int i = 0; i < PW; ++i) issue_w1(slot, ph, i);
+      for (int i = 0; i < PWR; ++i) issue_w1(slot, 1, c, i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < PWE; ++i) issue_w1(slot, 0, c, i);
+    }
   };
 
   // ---- per-tile descriptors of this wave's 16 RW rows (rows past M: outside the range -- loads give zeros, stores are dropped)
@@ -206,9 +219,9 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
   f32x4_t yacc[RW][QF];                                    // Y^T fragments: lane (r, g), register i <- row 16 rho + r, column 32 (q / 2) + 8 g + 4 (q % 2) + i
 
   long tile = blockIdx.x;
-  issue_w(0, 0);
-  issue_w(1, 1);
-  issue_w(2, 2);
+  issue_w(0, 0, 0);                                        // E(0), R(0), E(1): ring slot = tile phase & 3
+  issue_w(1, 1, 0);
+  issue_w(2, 0, 1);
   load_a(tile);
   {
     const __amdgpu_buffer_rsrc_t s = srd_of(p.res, tile, CX);
@@ -245,11 +258,11 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
       prwait_vm<CF::NE>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      // the pieces of phase p + 3 go into the slot everybody has just left, SPREAD over this phase's MFMAs (one per DGAP fragments): the
+      // the pieces of phase p + 3 go into the slot everybody has just left, SPREAD over this phase's MFMAs (one per DGE / DGR fragments): the
       // four waves' pieces issued in a row right behind the barrier queue up in the CU's one address unit, and every wave sits in its
       // issue stall with an idle matrix pipe (measured: 345 of 1745 us)
-      const int ph_e = 2 * c + 3 >= CF::NPH ? 2 * c + 3 - CF::NPH : 2 * c + 3;
-      constexpr int DGAP = CF::EF / PW;
+      const int c_e = c + 1 >= NCH ? c + 1 - NCH : c + 1;  // this phase issues the pieces of R(c + 1) (tile phase p + 3)
+      constexpr int DGE = CF::EF / PWR;
       f32x4_t zacc[RW][4];
       const char* const es = smem + CF::RING + SE * HALF + lane * 16;
       // (fragment f is read NB fragments ahead of its MFMAs into a rotating set of registers; the scheduling barriers keep hipcc from
@@ -268,7 +281,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (f + NB < CF::EF) wf[f % NB] = *reinterpret_cast<const bf16x8_t*>(es + (f + NB) * 1024);
-        if (f % DGAP == DGAP / 2) issue_w1((SE + 3) & 3, ph_e, f / DGAP);
+        if (f % DGE == DGE / 2) issue_w1((SE + 3) & 3, 1, c_e, f / DGE);
       }
       __builtin_amdgcn_sched_barrier(0);
       // (inline-asm MFMAs are invisible to the compiler's hazard recogniser: the accumulators are read by vector instructions below)
@@ -319,7 +332,8 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
       prwait_vm<CF::NR>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const int ph_r = 2 * c + 4 >= CF::NPH ? 2 * c + 4 - CF::NPH : 2 * c + 4;
+      const int c_r = c + 2 >= NCH ? c + 2 - NCH : c + 2;  // this phase issues the pieces of E(c + 2)
+      constexpr int DGR = CF::RF / PWE;
       const char* const rs = smem + CF::RING + SR * HALF + lane * 16;
 #pragma unroll
       for (int f = 0; f < NB; ++f) wf[f] = *reinterpret_cast<const bf16x8_t*>(rs + f * 1024);
@@ -336,7 +350,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (f + NB < CF::RF) wf[f % NB] = *reinterpret_cast<const bf16x8_t*>(rs + (f + NB) * 1024);
-        if (f % DGAP == DGAP / 2) issue_w1((SR + 3) & 3, ph_r, f / DGAP);
+        if (f % DGR == DGR / 2) issue_w1((SR + 3) & 3, 0, c_r, f / DGR);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -352,15 +366,16 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
     load_a(tnext);
 
     // ---------------- Y epilogue: statistics from the fp32 accumulators (rows past M masked), bf16 stores
-    const __amdgpu_buffer_rsrc_t srd_y = srd_of(p.y, tile, C);
+    const __amdgpu_buffer_rsrc_t srd_y = srd_of(p.y, tile, CR);
     const long row0 = tile * TM + wave * (16 * RW) + r;
     float mask[RW];
 #pragma unroll
     for (int rho = 0; rho < RW; ++rho) mask[rho] = row0 + 16 * rho < p.M ? 1.f : 0.f;
     unsigned stat_at;                                      // this lane's statistics columns 8 g .. (an opaque copy per tile: see `z` above)
     asm volatile("v_mov_b32 %0, %1" : "=v"(stat_at) : "v"((unsigned)(uintptr_t)(lstat + 8 * g)));
+    const int yo = r * (CR * 2) + g * 16;                  // + rho * 16 * CR * 2 + u * 64
 #pragma unroll
-    for (int u = 0; u < C / 32; ++u) {
+    for (int u = 0; u < CR / 32; ++u) {
       float s1[8], s2[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -378,7 +393,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
         bf16_t pk[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) pk[i] = (bf16_t)v[i];
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t*>(pk), srd_y, xo, rho * (16 * C * 2) + u * 64, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t*>(pk), srd_y, yo, rho * (16 * CR * 2) + u * 64, 0);
       }
       if (PAIR_ABL & 16) continue;
 #pragma unroll
@@ -388,7 +403,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
         //  and immediate offsets: with an address per sum hipcc keeps all 64 of them alive across the tile loop)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          asm volatile("ds_add_f32 %0, %1 offset:%3\n\tds_add_f32 %0, %2 offset:%4" ::"v"(stat_at), "v"(s1[i]), "v"(s2[i]), "n"((32 * u + i) * 4), "n"(C * 4 + (32 * u + i) * 4) : "memory");
+          asm volatile("ds_add_f32 %0, %1 offset:%3\n\tds_add_f32 %0, %2 offset:%4" ::"v"(stat_at), "v"(s1[i]), "v"(s2[i]), "n"((32 * u + i) * 4), "n"(CR * 4 + (32 * u + i) * 4) : "memory");
       }
     }
   }
@@ -397,8 +412,8 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
   __syncthreads();
   {
     const float* const all = reinterpret_cast<const float*>(smem + CF::STAT);
-    float* const row = p.stats + (long)blockIdx.x * (2 * C);
-    for (int k = threadIdx.x; k < 2 * C; k += 256) row[k] = (all[k] + all[2 * C + k]) + (all[4 * C + k] + all[6 * C + k]);
+    float* const row = p.stats + (long)blockIdx.x * (2 * CR);
+    for (int k = threadIdx.x; k < 2 * CR; k += 256) row[k] = (all[k] + all[2 * CR + k]) + (all[4 * CR + k] + all[6 * CR + k]);
   }
 }
 
@@ -406,20 +421,21 @@ template <typename CF, bool IN>
 __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(const PairArgs p) { pair_body<CF, IN>(p); }
 template <typename CF, bool IN> struct PairTag {};
 
-// ---- weight stream: [phase][fragment][lane][8 bf16]; phase 2 c = chunk c of the expansion (fragment kk * 4 + j), phase 2 c + 1 = K-slice
-// c of the reduce conv (fragment t * QF + q)
+// ---- weight stream: [chunk][EF + RF fragments][lane][8 bf16]: chunk c = the expansion's weights of Z columns 64 c .. + 63 (fragment kk * 4 + j),
+// then K-slice c of the reduce conv (fragment t * QF + q)
 template <typename CF>
 __global__ void pair_pack_kernel(const bf16_t* __restrict__ w3, const bf16_t* __restrict__ w1, uint4* __restrict__ out) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte piece each
-  if (id >= CF::NPH * CF::EF * 64) return;
-  const int lane = id & 63, f = (id >> 6) % CF::EF, ph = id / (64 * CF::EF);
-  const int m = lane & 15, g = lane >> 4, c = ph >> 1;
+  constexpr int FPC = CF::EF + CF::RF;
+  if (id >= CF::NCH * FPC * 64) return;
+  const int lane = id & 63, f = (id >> 6) % FPC, c = id / (64 * FPC);
+  const int m = lane & 15, g = lane >> 4;
   const bf16_t* src;
-  if ((ph & 1) == 0) {
+  if (f < CF::EF) {
     const int kk = f / 4, j = f % 4;
     src = w3 + (long)(64 * c + pair_sigma(j, m)) * CF::C + 32 * kk + 8 * g;
   } else {
-    const int t = f / CF::QF, q = f % CF::QF;
+    const int t = (f - CF::EF) / CF::QF, q = (f - CF::EF) % CF::QF;
     src = w1 + (long)pair_sigma(q, m) * CF::CX + 64 * c + 32 * t + 8 * g;
   }
   out[id] = *reinterpret_cast<const uint4*>(src);
@@ -429,19 +445,19 @@ inline bool pair_enabled() {
   static const bool off = [] { const char* e = getenv("SR_NO_PAIR"); return e && e[0] == '1'; }();
   return !off;
 }
-inline bool pair_shape_ok(long M, int C, int CX) {
-  return pair_enabled() && (C == 256 || C == 128 || C == 64) && CX == 4 * C && M >= 1 && M <= 0x7fffffffL;
+// (Cmid, Cexp, Cred): inside a layer Cred = Cmid (256 / 128 / 64); across a layer boundary Cred = 2 Cmid (128 / 64)
+inline bool pair_shape_ok(long M, int C, int CX, int CR) {
+  return pair_enabled() && CX == 4 * C && M >= 1 && M <= 0x7fffffffL &&
+         ((CR == C && (C == 256 || C == 128 || C == 64)) || (CR == 2 * C && (C == 128 || C == 64)));
 }
 template <typename CF>
 inline unsigned pair_grid(long M) {
   const long ntiles = (M + CF::TM - 1) / CF::TM, cus = sr_num_cus();
   return (unsigned)(ntiles < cus ? ntiles : cus);
 }
-inline unsigned pair_grid_c(long M, int C) { return C == 256 ? pair_grid<PairL3>(M) : (C == 128 ? pair_grid<PairL2>(M) : pair_grid<PairL1>(M)); }
-
 template <typename CF>
 int pair_pack_launch(const void* w_exp, const void* w_red, void* out, hipStream_t st) {
-  const int n = CF::NPH * CF::EF * 64;
+  const int n = CF::NCH * (CF::EF + CF::RF) * 64;
   hipLaunchKernelGGL(pair_pack_kernel<CF>, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16_t*)w_exp, (const bf16_t*)w_red, (uint4*)out);
   SR_CHECK_LAUNCH();
   return SR_OK;
@@ -458,38 +474,45 @@ int pair_launch(const PairArgs& s, hipStream_t st) {
   const unsigned grid = pair_grid<CF>(s.M);
   return s.in_scale ? pair_launch_v<CF, true>(s, grid, st) : pair_launch_v<CF, false>(s, grid, st);
 }
+// one call per configuration: f(PairCfgTag<Cfg>{})
+template <typename CF> struct PairCfgTag { typedef CF type; };
+template <typename F>
+inline auto pair_dispatch(int C, int CR, F&& f) {
+  if (CR == C) return C == 256 ? f(PairCfgTag<PairL3>{}) : (C == 128 ? f(PairCfgTag<PairL2>{}) : f(PairCfgTag<PairL1>{}));
+  return C == 128 ? f(PairCfgTag<PairL23>{}) : f(PairCfgTag<PairL12>{});
+}
 
 }  // namespace
 
-extern "C" int sr_conv_pair_supported(int64_t M, int Cmid, int Cexp, int dtype) {
-  return dtype == SR_BF16 && pair_shape_ok(M, Cmid, Cexp) ? 1 : 0;
+extern "C" int sr_conv_pair_supported(int64_t M, int Cmid, int Cexp, int Cred, int dtype) {
+  return dtype == SR_BF16 && pair_shape_ok(M, Cmid, Cexp, Cred) ? 1 : 0;
 }
-extern "C" int sr_conv_pair_pack_bytes(int Cmid, int Cexp) {
-  if (!pair_shape_ok(1, Cmid, Cexp)) return SR_ERR_UNSUPPORTED;
-  return 2 * Cmid * Cexp * 2;
+extern "C" int sr_conv_pair_pack_bytes(int Cmid, int Cexp, int Cred) {
+  if (!pair_shape_ok(1, Cmid, Cexp, Cred)) return SR_ERR_UNSUPPORTED;
+  return (Cmid + Cred) * Cexp * 2;
 }
-extern "C" int sr_conv_pair_stats_rows(int64_t M, int Cmid, int Cexp) {
-  if (!pair_shape_ok(M, Cmid, Cexp)) return SR_ERR_UNSUPPORTED;
-  return (int)pair_grid_c(M, Cmid);
+extern "C" int sr_conv_pair_stats_rows(int64_t M, int Cmid, int Cexp, int Cred) {
+  if (!pair_shape_ok(M, Cmid, Cexp, Cred)) return SR_ERR_UNSUPPORTED;
+  return (int)pair_dispatch(Cmid, Cred, [&](auto tag) { return pair_grid<typename decltype(tag)::type>(M); });
 }
-extern "C" int sr_conv_pair_pack(const void* w_exp, const void* w_red, void* out, int Cmid, int Cexp, int dtype, void* stream) {
+extern "C" int sr_conv_pair_pack(const void* w_exp, const void* w_red, void* out, int Cmid, int Cexp, int Cred, int dtype, void* stream) {
   if (!w_exp || !w_red || !out) return SR_ERR_ARG;
   if (dtype != SR_BF16) return SR_ERR_DTYPE;
-  if (!pair_shape_ok(1, Cmid, Cexp)) return SR_ERR_UNSUPPORTED;
+  if (!pair_shape_ok(1, Cmid, Cexp, Cred)) return SR_ERR_UNSUPPORTED;
   if (((uintptr_t)w_exp | (uintptr_t)w_red | (uintptr_t)out) & 15) return SR_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  return Cmid == 256 ? pair_pack_launch<PairL3>(w_exp, w_red, out, st)
-                     : (Cmid == 128 ? pair_pack_launch<PairL2>(w_exp, w_red, out, st) : pair_pack_launch<PairL1>(w_exp, w_red, out, st));
+  return pair_dispatch(Cmid, Cred, [&](auto tag) { return pair_pack_launch<typename decltype(tag)::type>(w_exp, w_red, out, st); });
 }
 extern "C" int sr_conv_pair(const sr_pair_args* a, int dtype, void* stream) {
   if (!a || !a->x || !a->wpack || !a->res || !a->z || !a->y || !a->escale || !a->eshift || !a->stats || a->M <= 0) return SR_ERR_ARG;
   if (dtype != SR_BF16) return SR_ERR_DTYPE;
   if ((a->in_scale == nullptr) != (a->in_shift == nullptr)) return SR_ERR_ARG;
   if (((uintptr_t)a->x | (uintptr_t)a->wpack | (uintptr_t)a->res | (uintptr_t)a->z | (uintptr_t)a->y) & 15) return SR_ERR_ARG;
-  if (!pair_shape_ok(a->M, a->Cmid, a->Cexp)) return SR_ERR_UNSUPPORTED;
+  const int cred = a->Cred ? a->Cred : a->Cmid;
+  if (!pair_shape_ok(a->M, a->Cmid, a->Cexp, cred)) return SR_ERR_UNSUPPORTED;
   PairArgs s;
   s.x = (const bf16_t*)a->x; s.wpack = (const bf16_t*)a->wpack; s.res = (const bf16_t*)a->res; s.z = (bf16_t*)a->z; s.y = (bf16_t*)a->y;
   s.escale = a->escale; s.eshift = a->eshift; s.in_scale = a->in_scale; s.in_shift = a->in_shift; s.stats = a->stats; s.M = a->M;
   hipStream_t st = (hipStream_t)stream;
-  return a->Cmid == 256 ? pair_launch<PairL3>(s, st) : (a->Cmid == 128 ? pair_launch<PairL2>(s, st) : pair_launch<PairL1>(s, st));
+  return pair_dispatch(a->Cmid, cred, [&](auto tag) { return pair_launch<typename decltype(tag)::type>(s, st); });
 }

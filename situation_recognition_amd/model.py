@@ -327,8 +327,8 @@ class resnet(nn.Module):
         """Is expansion unit `u` followed by reduce unit `nxt` (the next block's conv1, fed this block's output and nothing else) served
         by the fused launch `sr_conv_pair`?"""
         return (self.fuse_pairs and nxt is not None and self.dtype == torch.bfloat16 and u.k == 1 and u.stride == 1 and nxt.k == 1
-                and nxt.stride == 1 and nxt.pad == 0 and nxt.cin_p == u.cout_p and nxt.cout_p == u.cin_p and n_pixels >= 128 * 256
-                and ops.conv_pair_supported(n_pixels, u.cin_p, u.cout_p, self.dtype))
+                and nxt.stride == 1 and nxt.pad == 0 and nxt.cin_p == u.cout_p and n_pixels >= 128 * 256
+                and ops.conv_pair_supported(n_pixels, u.cin_p, u.cout_p, nxt.cout_p, self.dtype))
 
     def _unit(self, x, u, train, momentum, relu, res=None, stem_hw=None, pool_after=False, then=None, twin=None, quant_out=False,
               pre=None, fuse_next=None):
@@ -436,13 +436,14 @@ class resnet(nn.Module):
         return ops.bn_apply(y, scale, shift, res=res, relu=relu, out=y)
 
     def _next_reduce(self, bi, train):
-        """The conv1 unit of block bi + 1 when it may run fused with block bi's expansion conv: train mode, a bottleneck whose only
-        reader of block bi's output besides the identity path is that 1x1 / stride-1 conv (no downsample branch), else None."""
+        """The conv1 unit of block bi + 1 when it may run fused with block bi's expansion conv: train mode, both blocks bottlenecks.
+        (Across a layer boundary the next block's downsample branch reads block bi's output as well: the output is written either
+        way, what the fused launch saves is conv1's read of it.)  Shapes are checked by `_pair_ok`."""
         blocks = self._plan()[1]
         if not (train and self.fuse_pairs) or bi + 1 >= len(blocks):
             return None
         convs, ds = blocks[bi + 1]
-        return convs[0] if ds is None and len(convs) == 3 and len(blocks[bi][0]) == 3 else None
+        return convs[0] if len(convs) == 3 and len(blocks[bi][0]) == 3 else None
 
     def _run_block(self, a, bi, train, momentum, tblock=None, T=lambda tu: None, pre=None, fuse_next=False):
         """One residual block on the NHWC activation `a` (torchvision Bottleneck / BasicBlock: conv-BN-ReLU chain, optional

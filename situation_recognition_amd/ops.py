@@ -196,40 +196,45 @@ def conv2d(x, w, Cout, KH, stride, pad, bias=None, res=None, relu=False, want_st
     return (y, stats) if want_stats else y
 
 
-def conv_pair_supported(M, Cmid, Cexp, dtype=torch.bfloat16):
-    """Does sr_conv_pair (expansion conv fused with the next block's reduce conv) serve this shape?"""
-    return dtype == torch.bfloat16 and lib().sr_conv_pair_supported(int(M), int(Cmid), int(Cexp), L.SR_BF16) == 1
+def conv_pair_supported(M, Cmid, Cexp, Cred=None, dtype=torch.bfloat16):
+    """Does sr_conv_pair (expansion conv fused with the next block's reduce conv, Cred output channels: Cmid inside a layer, 2 Cmid
+    across a layer boundary) serve this shape?"""
+    Cred = Cmid if Cred is None else Cred
+    return dtype == torch.bfloat16 and lib().sr_conv_pair_supported(int(M), int(Cmid), int(Cexp), int(Cred), L.SR_BF16) == 1
 
 
 def conv_pair_pack(w_exp, w_red):
-    """Packed weight stream of sr_conv_pair: w_exp [Cexp, Cmid] (the expansion conv), w_red [Cmid, Cexp] (the next block's reduce conv)."""
+    """Packed weight stream of sr_conv_pair: w_exp [Cexp, Cmid] (the expansion conv), w_red [Cred, Cexp] (the next block's reduce conv)."""
     require_gpu(w_exp, w_red)
     Cexp, Cmid = w_exp.shape
-    if tuple(w_red.shape) != (Cmid, Cexp) or w_exp.dtype != torch.bfloat16 or w_red.dtype != torch.bfloat16:
-        raise L.SrError("conv_pair_pack: expected bf16 w_exp [Cexp, Cmid] and w_red [Cmid, Cexp]")
-    nbytes = lib().sr_conv_pair_pack_bytes(Cmid, Cexp)
+    Cred = w_red.shape[0]
+    if w_red.shape[1] != Cexp or w_exp.dtype != torch.bfloat16 or w_red.dtype != torch.bfloat16:
+        raise L.SrError("conv_pair_pack: expected bf16 w_exp [Cexp, Cmid] and w_red [Cred, Cexp]")
+    nbytes = lib().sr_conv_pair_pack_bytes(Cmid, Cexp, Cred)
     check(min(nbytes, 0), "sr_conv_pair_pack_bytes")
     out = torch.empty(nbytes // 2, device=w_exp.device, dtype=torch.bfloat16)
-    check(lib().sr_conv_pair_pack(w_exp.data_ptr(), w_red.data_ptr(), out.data_ptr(), Cmid, Cexp, L.SR_BF16, stream()), "sr_conv_pair_pack")
+    check(lib().sr_conv_pair_pack(w_exp.data_ptr(), w_red.data_ptr(), out.data_ptr(), Cmid, Cexp, Cred, L.SR_BF16, stream()), "sr_conv_pair_pack")
     return out
 
 
 def conv_pair(x, wpack, res, escale, eshift, in_affine=None):
     """z = relu((f(x) @ w_exp.T) * escale + eshift + res), y = z @ w_red.T (raw) and y's BatchNorm partials in one launch (sr_conv_pair);
-    f = relu(x*in_scale + in_shift) with in_affine, identity without.  x: NHWC [B,H,W,Cmid], res: [B,H,W,Cexp].  Returns (z, y, stats)."""
+    f = relu(x*in_scale + in_shift) with in_affine, identity without.  x: NHWC [B,H,W,Cmid], res: [B,H,W,Cexp]; the reduce conv's width
+    follows from the weight stream's size.  Returns (z, y [B,H,W,Cred], stats)."""
     require_gpu(x, wpack, res, escale, eshift)
     B, H, W_, Cmid = x.shape
     Cexp = res.shape[3]
     M = B * H * W_
     if tuple(res.shape) != (B, H, W_, Cexp) or x.dtype != torch.bfloat16 or res.dtype != torch.bfloat16 or wpack.dtype != torch.bfloat16:
         raise L.SrError("conv_pair: shape/dtype mismatch")
-    if wpack.numel() != 2 * Cmid * Cexp or escale.numel() != Cexp or eshift.numel() != Cexp:
+    Cred = wpack.numel() // Cexp - Cmid
+    if wpack.numel() != (Cmid + Cred) * Cexp or Cred <= 0 or escale.numel() != Cexp or eshift.numel() != Cexp:
         raise L.SrError("conv_pair: weight stream / scale vectors do not match (Cmid, Cexp)")
-    rows = lib().sr_conv_pair_stats_rows(M, Cmid, Cexp)
+    rows = lib().sr_conv_pair_stats_rows(M, Cmid, Cexp, Cred)
     check(min(rows, 0), "sr_conv_pair_stats_rows")
     z = torch.empty_like(res)
-    y = torch.empty_like(x)
-    stats = torch.empty((rows, 2, Cmid), device=x.device, dtype=torch.float32)
+    y = torch.empty((B, H, W_, Cred), device=x.device, dtype=x.dtype)
+    stats = torch.empty((rows, 2, Cred), device=x.device, dtype=torch.float32)
     a = L.PairArgs()
     a.x, a.wpack, a.res, a.z, a.y = x.data_ptr(), wpack.data_ptr(), res.data_ptr(), z.data_ptr(), y.data_ptr()
     a.escale, a.eshift = _f32(escale, "escale").data_ptr(), _f32(eshift, "eshift").data_ptr()
@@ -238,9 +243,9 @@ def conv_pair(x, wpack, res, escale, eshift, in_affine=None):
         if in_affine[0].numel() != Cmid or in_affine[1].numel() != Cmid:
             raise L.SrError("conv_pair: in_affine must have Cmid elements")
         a.in_scale, a.in_shift = _f32(in_affine[0], "in_scale").data_ptr(), _f32(in_affine[1], "in_shift").data_ptr()
-    a.stats, a.M, a.Cmid, a.Cexp = stats.data_ptr(), M, Cmid, Cexp
-    flops = 4.0 * M * Cmid * Cexp
-    nbytes = 2.0 * (2 * M * Cmid + 2 * M * Cexp + 2 * Cmid * Cexp)     # x, res read; z, y written; both weight matrices once
+    a.stats, a.M, a.Cmid, a.Cexp, a.Cred = stats.data_ptr(), M, Cmid, Cexp, Cred
+    flops = 2.0 * M * Cexp * (Cmid + Cred)
+    nbytes = 2.0 * (M * Cmid + 2 * M * Cexp + M * Cred + (Cmid + Cred) * Cexp)     # x, res read; z, y written; both weight matrices once
     check(_timed("conv1x1_pair", flops, nbytes, lambda: lib().sr_conv_pair(C.byref(a), L.SR_BF16, stream())), "sr_conv_pair")
     return z, y, stats
 

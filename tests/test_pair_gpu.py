@@ -9,7 +9,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
-SHAPES = {"layer3": (14, 256), "layer2": (28, 128), "layer1": (56, 64)}     # (image side, mid channels); expansion = 4 x mid
+# (image side, mid channels, output channels of the reduce conv): expansion = 4 x mid; "a>b": layer a's last block + layer b's first conv1
+SHAPES = {"layer3": (14, 256, 256), "layer2": (28, 128, 128), "layer1": (56, 64, 64), "layer2>3": (28, 128, 256), "layer1>2": (56, 64, 128)}
+TILE_ROWS = {"layer3": 192, "layer2": 256, "layer1": 256, "layer2>3": 192, "layer1>2": 256}
 
 
 @pytest.fixture(scope="module")
@@ -22,20 +24,20 @@ def ops():
 
 
 def operands(B, seed, layer="layer3"):
-    H, C = SHAPES[layer]
+    H, C, CR = SHAPES[layer]
     CX = 4 * C
     g = torch.Generator(device="cuda").manual_seed(seed)
     x = torch.randn(B, H, H, C, device="cuda", generator=g).to(BF)                       # raw 3x3 output
     res = torch.relu(torch.randn(B, H, H, CX, device="cuda", generator=g)).to(BF)        # identity: a block output
     w3 = (torch.randn(CX, C, device="cuda", generator=g) * C ** -0.5).to(BF)
-    w1 = (torch.randn(C, CX, device="cuda", generator=g) * CX ** -0.5).to(BF)
+    w1 = (torch.randn(CR, CX, device="cuda", generator=g) * CX ** -0.5).to(BF)
     insc, insh = 0.5 + torch.rand(C, device="cuda", generator=g), 0.1 * torch.randn(C, device="cuda", generator=g)
     esc, esh = 0.2 + 0.3 * torch.rand(CX, device="cuda", generator=g), 0.1 * torch.randn(CX, device="cuda", generator=g)
     return x, res, w3, w1, (insc, insh), esc, esh
 
 
 def fp32_reference(x, res, w3, w1, aff, esc, esh, rows):
-    C, CX = w1.shape
+    CX, C = w3.shape
     M = x.numel() // C
     xa = x.view(M, C)[rows].float()
     if aff is not None:
@@ -44,24 +46,25 @@ def fp32_reference(x, res, w3, w1, aff, esc, esh, rows):
     return z
 
 
-@pytest.mark.parametrize("layer,B,in_affine", [("layer3", 1024, True), ("layer3", 1024, False), ("layer2", 301, True), ("layer1", 75, True)])
+@pytest.mark.parametrize("layer,B,in_affine", [("layer3", 1024, True), ("layer3", 1024, False), ("layer2", 301, True), ("layer1", 75, True),
+                                               ("layer2>3", 253, True), ("layer1>2", 75, False)])
 def test_pair_equals_the_two_launches_it_replaces(ops, layer, B, in_affine):
     """Layer3 at batch 1024: 1046 tiles of 192 rows (the last one ragged: 64 rows, two waves of it empty) on 256 workgroups = 4 tiles
     each; layer2 / layer1 (256-row tiles) at batches with as many rows and a ragged last tile."""
-    H, C = SHAPES[layer]
+    H, C, CR = SHAPES[layer]
     CX = 4 * C
     x, res, w3, w1, aff, esc, esh = operands(B, 21, layer)
     M = B * H * H
-    TM = 192 if layer == "layer3" else 256
+    TM = TILE_ROWS[layer]
     assert M % TM != 0 and (M + TM - 1) // TM >= 3 * 256
     if not in_affine:
         x = torch.relu(x.float() * aff[0] + aff[1]).to(BF)
         aff = None
     from situation_recognition_amd import _lib
     assert ops.conv_route(B, H, H, C, CX, 1, 1, 0, res=True, relu=True, bias=True, escale=True, in_affine=in_affine) == _lib.ROUTE_WS
-    assert ops.conv_route(B, H, H, CX, C, 1, 1, 0, want_stats=True) == ops.conv_route(6144, H, H, CX, C, 1, 1, 0, want_stats=True)
+    assert ops.conv_route(B, H, H, CX, CR, 1, 1, 0, want_stats=True) == ops.conv_route(6144, H, H, CX, CR, 1, 1, 0, want_stats=True)
     z0 = ops.conv2d(x, w3, CX, 1, 1, 0, bias=esh, escale=esc, res=res, relu=True, in_affine=aff)
-    y0, st0 = ops.conv2d(z0, w1, C, 1, 1, 0, want_stats=True)
+    y0, st0 = ops.conv2d(z0, w1, CR, 1, 1, 0, want_stats=True)
     wp = ops.conv_pair_pack(w3, w1)
     z1, y1, st1 = ops.conv_pair(x, wp, res, esc, esh, in_affine=aff)
     assert torch.equal(z0.view(torch.int16), z1.view(torch.int16))
@@ -75,7 +78,7 @@ def test_pair_equals_the_two_launches_it_replaces(ops, layer, B, in_affine):
     zr = fp32_reference(x, res, w3, w1, aff, esc, esh, rows)
     assert float((zr - z1.view(M, CX)[rows].float()).abs().max()) <= 1.2e-2 * float(zr.abs().max())
     yr = z1.view(M, CX)[rows].float() @ w1.float().t()
-    assert float((yr - y1.view(M, C)[rows].float()).abs().max()) <= 1.2e-2 * float(yr.abs().max())
+    assert float((yr - y1.view(M, CR)[rows].float()).abs().max()) <= 1.2e-2 * float(yr.abs().max())
     # statistics = column sums / sums of squares of the fp32 product over ALL rows (rows past M contribute nothing)
     yf = (z1.view(M, CX).float() @ w1.float().t()).double()
     assert float((yf.sum(0) - s1[0]).abs().max() / s1[0].abs().max()) < 1e-5
@@ -87,21 +90,22 @@ def test_pair_equals_the_two_launches_it_replaces(ops, layer, B, in_affine):
         assert torch.equal(st1, st2)
 
 
-@pytest.mark.parametrize("layer,B", [("layer3", 1), ("layer3", 3), ("layer3", 700), ("layer2", 1), ("layer2", 50), ("layer1", 1), ("layer1", 9)])
+@pytest.mark.parametrize("layer,B", [("layer3", 1), ("layer3", 3), ("layer3", 700), ("layer2", 1), ("layer2", 50), ("layer1", 1), ("layer1", 9),
+                                     ("layer2>3", 1), ("layer2>3", 41), ("layer1>2", 2)])
 def test_pair_small_and_ragged_row_counts(ops, layer, B):
     """One tile and a few rows, grids smaller than the chip; against the fp32 reference over all rows."""
-    H, C = SHAPES[layer]
+    H, C, CR = SHAPES[layer]
     CX = 4 * C
     x, res, w3, w1, aff, esc, esh = operands(B, 30 + B, layer)
     M = B * H * H
-    TM = 192 if layer == "layer3" else 256
+    TM = TILE_ROWS[layer]
     wp = ops.conv_pair_pack(w3, w1)
     z1, y1, st1 = ops.conv_pair(x, wp, res, esc, esh, in_affine=aff)
     rows = torch.arange(0, M, device="cuda")
     zr = fp32_reference(x, res, w3, w1, aff, esc, esh, rows)
     assert float((zr - z1.view(M, CX).float()).abs().max()) <= 1.2e-2 * float(zr.abs().max())
     yf = z1.view(M, CX).float() @ w1.float().t()
-    assert float((yf - y1.view(M, C).float()).abs().max()) <= 1.2e-2 * float(yf.abs().max())
+    assert float((yf - y1.view(M, CR).float()).abs().max()) <= 1.2e-2 * float(yf.abs().max())
     s1 = st1.double().sum(0)
     assert st1.shape[0] == min(256, (M + TM - 1) // TM)
     assert float((yf.double().sum(0) - s1[0]).abs().max() / s1[0].abs().max()) < 1e-5
@@ -112,8 +116,10 @@ def test_pair_rejects_what_it_does_not_serve(ops):
     from situation_recognition_amd import _lib
     assert ops.conv_pair_supported(200704, 256, 1024)
     assert ops.conv_pair_supported(200704, 128, 512) and ops.conv_pair_supported(200704, 64, 256)
+    assert ops.conv_pair_supported(200704, 128, 512, 256) and ops.conv_pair_supported(200704, 64, 256, 128)
     assert not ops.conv_pair_supported(200704, 512, 2048) and not ops.conv_pair_supported(200704, 256, 512)
-    assert not ops.conv_pair_supported(200704, 256, 1024, torch.float32)
+    assert not ops.conv_pair_supported(200704, 256, 1024, 512)         # layer3 -> layer4: 512 reduce outputs do not fit the accumulators
+    assert not ops.conv_pair_supported(200704, 256, 1024, dtype=torch.float32)
     x, res, w3, w1, aff, esc, esh = operands(2, 3)
     wp = ops.conv_pair_pack(w3, w1)
     with pytest.raises(_lib.SrError):
