@@ -39,7 +39,7 @@
 
 // Diagnostic builds only (tools/pair_ablation.sh; results are garbage, the TIME of what is left is the measurement): bit 0 no MFMAs,
 // bit 1 no HBM traffic (X / identity loads, Z / Y stores), bit 2 no weight stream (LDS-DMA), bit 3 no Z epilogue arithmetic, bit 4 no
-// statistics reduction.
+// statistics reduction, bit 11 Z stores / identity loads as 8 rows x 128 B per instruction (misplaced data, same bytes).
 #ifndef PAIR_ABL
 #define PAIR_ABL 0
 #endif
@@ -197,7 +197,14 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(base + m0 * ld), 0, (PAIR_ABL & 2) ? 0 : (int)(rows * ld * 2), 0x00020000);
   };
   const int xo = r * (C * 2) + g * 16;                     // + rho * 16 * C * 2 + kk * 64
+#if PAIR_ABL & 2048
+  // (diagnostic: every store / load instruction covers 8 rows x 128 contiguous bytes instead of 16 rows x 64 -- t selects the row half)
+  const int zo = (r & 7) * (CX * 2) + (r >> 3) * 64 + g * 16;
+#define PR_ZOFF(rho, c, t) ((rho) * (16 * CX * 2) + (t) * (8 * CX * 2) + (64 * (c)) * 2)
+#else
   const int zo = r * (CX * 2) + g * 16;                    // + rho * 16 * CX * 2 + (64 c + 32 t) * 2
+#define PR_ZOFF(rho, c, t) ((rho) * (16 * CX * 2) + (64 * (c) + 32 * (t)) * 2)
+#endif
 
   u32x4_t a[RW][KT];                                       // X in B-operand layout: lane (r, g) <- row 16 rho + r, channels 32 kk + 8 g .. + 7
   auto load_a = [&](long tile) {
@@ -213,7 +220,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
 #pragma unroll
     for (int rho = 0; rho < RW; ++rho)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) idn[buf][rho][t] = __builtin_amdgcn_raw_buffer_load_b128(s, zo, rho * (16 * CX * 2) + (64 * c + 32 * t) * 2, 0);
+      for (int t = 0; t < 2; ++t) idn[buf][rho][t] = __builtin_amdgcn_raw_buffer_load_b128(s, zo, PR_ZOFF(rho, c, t), 0);
   };
 
   f32x4_t yacc[RW][QF];                                    // Y^T fragments: lane (r, g), register i <- row 16 rho + r, column 32 (q / 2) + 8 g + 4 (q % 2) + i
@@ -302,7 +309,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
             u32x4_t keep = a[rho][t] ^ iv;                 // (one read per accumulator fragment keeps the E phase alive)
             keep[0] ^= __float_as_uint(pracc(zacc[rho][2 * t], 0)) ^ __float_as_uint(pracc(zacc[rho][2 * t + 1], 0));
             zb[rho][t] = __builtin_bit_cast(bf16x8_t, keep);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, zb[rho][t]), srd_z, zo, rho * (16 * CX * 2) + (64 * c + 32 * t) * 2, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, zb[rho][t]), srd_z, zo, PR_ZOFF(rho, c, t), 0);
             continue;
           }
 #pragma unroll
@@ -322,7 +329,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
             asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk[k]) : "v"(pk[k]));
           }
           zb[rho][t] = __builtin_bit_cast(bf16x8_t, pk);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, zb[rho][t]), srd_z, zo, rho * (16 * CX * 2) + (64 * c + 32 * t) * 2, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, zb[rho][t]), srd_z, zo, PR_ZOFF(rho, c, t), 0);
         }
       }
       // identity of the chunk after next (the first two chunks of the next tile at a tile's end) into the buffer just consumed
