@@ -53,8 +53,8 @@ def apply_key(x, scale, shift, res=None, relu=True, out=None):
 wrap("conv2d", conv_key)
 wrap("bn_apply", apply_key)
 wrap("conv_pair", lambda x, wp, res, esc, esh, in_affine=None: (
-    "pair 1x1 %4d->%4d->%4d @%3d %s" % (x.shape[3], res.shape[3], x.shape[3], x.shape[1], "ERAS" if in_affine is not None else "ERS"),
-    4.0 * x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * res.shape[3], 2.0 * (2 * x.numel() + 2 * res.numel())))
+    "pair 1x1 %4d->%4d->%4d @%3d %s" % (x.shape[3], res.shape[3], wp.numel() // res.shape[3] - x.shape[3], x.shape[1], "ERAS" if in_affine is not None else "ERS"),
+    2.0 * x.shape[0] * x.shape[1] * x.shape[2] * wp.numel(), 2.0 * (x.numel() + 2 * res.numel() + x.numel() // x.shape[3] * (wp.numel() // res.shape[3] - x.shape[3]))))
 wrap("gram", lambda x: ("gram C=%4d M=%d" % (x.shape[1], x.shape[0]), 2.0 * x.shape[0] * x.shape[1] ** 2, 2.0 * x.numel()))
 wrap("bn_apply_gram", lambda x, sc, sh: ("bn_apply+gram C=%4d M=%d" % (x.shape[1], x.shape[0]), 2.0 * x.shape[0] * x.shape[1] ** 2, 4.0 * x.numel()))
 wrap("bn_gram", lambda x, sc, sh: ("bn+gram (no write) C=%4d M=%d" % (x.shape[1], x.shape[0]), 2.0 * x.shape[0] * x.shape[1] ** 2, 2.0 * x.numel()))
