@@ -1,36 +1,39 @@
 // A bottleneck's expansion conv FUSED with the next block's reduce conv, for gfx950 (train mode, bf16):
 //
 //     Z[M, 4C] = relu( (relu(X*in_scale + in_shift) . W3[4C, C]^T) * escale + eshift + R[M, 4C] )          block output (written)
-//     Y[M, C]  = Z . W1[C, 4C]^T                                                                           next block's conv1, RAW (written)
+//     Y[M, CR] = Z . W1[CR, 4C]^T                                                                          next block's conv1, RAW (written)
 //     stats    = per-workgroup column sums / sums of squares of Y's fp32 accumulators                       (bn1 of the next block)
 //
-// torchvision chain replaced: conv3 -> bn3 -> (+identity) -> relu -> next.conv1 (call site: reference model.py:35).  Unfused, the block
-// output Z (4 units of M x C x 2 B) is written by the expansion conv and read back by the reduce conv: of the pair's 14 units of HBM
-// traffic (X 1, R 4, Z 4 | Z 4, Y 1) the 4-unit re-read goes -- 8.63 -> 6.17 GB per layer3 block at batch 6144 -- and the reduce
-// conv (under both of its roofs on the generic 256 x 256 tile) runs inside the expansion's HBM time.
+// torchvision chain replaced: conv3 -> bn3 -> (+identity) -> relu -> next.conv1 (call site: reference model.py:35); CR = C inside a layer, 2 C
+// where the next block opens the next layer.  Unfused, the block output Z (4 units of M x C x 2 B) is written by the expansion conv and read
+// back by the reduce conv: of the pair's 14 units of HBM traffic (X 1, R 4, Z 4 | Z 4, Y 1) the 4-unit re-read goes -- 8.63 -> 6.17 GB per
+// layer3 pair at batch 6144 (PMC: 6.38 GB) -- and the reduce conv's MFMAs run in the same pass.
 //
-// Design.  Both GEMMs are split by ROWS over the four waves of a workgroup (one wave per SIMD, 512 registers): a wave owns RW = 3 row
-// fragments (48 rows) of the 192-row tile for ALL columns, so the chain X -> Z -> Y never leaves the wave:
+// Design.  Both GEMMs are split by ROWS over the four waves of a workgroup (one wave per SIMD, up to 512 registers): a wave owns RW row
+// fragments (48 rows of a 192-row tile at C = 256, 64 of 256 at C = 128 / 64) for ALL columns, so the chain X -> Z -> Y never leaves the wave:
 //   * MFMA operands are arranged so that every product comes out TRANSPOSED (weights as the A operand, activations as B): the
 //     accumulator of v_mfma_f32_16x16x32_bf16 then holds, per lane, 4 consecutive COLUMNS of one tile row.  The expansion's weight
-//     rows are permuted inside a 32-column group (sigma below) so that two accumulator fragments, rounded to bf16, are exactly the
+//     rows are permuted inside a 32-column group (pair_sigma) so that two accumulator fragments, rounded to bf16, are exactly the
 //     16 bytes a lane needs (a) for a row-major global store of Z, (b) for the residual it adds, and (c) as the B operand of the
 //     reduce GEMM's K-step (k = 8 (lane / 16) .. + 7: the natural operand layout).  Z goes from accumulators to operand registers
 //     without touching LDS, and the same permutation on W1's rows makes Y's accumulators 16-byte row-major stores as well.
-//   * X (the tile's 48 rows x C channels per wave) is loaded ONCE per tile into 96 registers in B-operand layout and normalised there
+//   * X (the tile's rows x C channels per wave) is loaded ONCE per tile into registers in B-operand layout and normalised there
 //     (BatchNorm + ReLU of the 3x3 in front, `sr_affine_relu_chunk`: the same function the unfused expansion kernel applies).
-//   * Z's columns are walked in chunks of 64: E phase (K = C: 8 K-steps x 4 weight fragments x 3 row fragments = 96 MFMAs into 48
-//     accumulator registers), epilogue (scale / shift, + identity, ReLU, bf16, store), R phase (K = 64: 2 K-steps x 16 weight
-//     fragments x 3 = 96 MFMAs into the 192 accumulator registers of Y, which live across all 16 chunks of the tile).
+//   * Z's columns are walked in chunks of 64: E phase (K = C; at C = 256: 8 K-steps x 4 weight fragments x 3 row fragments = 96 MFMAs into
+//     48 accumulator registers), epilogue (scale / shift, + identity, ReLU on the packed pair, bf16, store), R phase (K = 64; 2 K-steps x
+//     CR / 16 weight fragments x RW MFMAs into Y's accumulators -- 192 AccVGPRs at C = CR = 256 -- which live across all chunks of the tile).
 //   * Only the WEIGHTS go through LDS: both matrices, pre-packed in exactly the order the phases consume them (sr_conv_pair_pack: one
-//     linear 1 MiB stream per tile, a fragment = 1 KiB in lane order, so reads are conflict-free by construction and the LDS-DMA copies
-//     1 KiB runs), through a ring of four 32 KiB slots (one slot = one phase's 32 fragments), filled by all four waves three phases
+//     linear stream per tile -- 1 MiB at C = 256 --, a fragment = 1 KiB in lane order, so reads are conflict-free by construction and the
+//     LDS-DMA copies 1 KiB runs), through a ring of four slots (one slot = one phase's fragments), filled by all four waves three phases
 //     ahead.  One workgroup barrier per phase: behind it everybody's pieces of this phase have landed (own counted vmcnt in front) and
-//     everybody has finished the previous phase's slot, which is refilled at once.  One ds_read_b128 per 3 MFMAs.
-//   * The identity is prefetched two chunks ahead into registers (2 x 24), X of the next tile during the current tile's last R phase.
-// Per tile and CU: 983 KB of HBM traffic (~98 K cycles at the ~10 B/clk a CU gets) against 3072 MFMAs per SIMD (49 K cycles): the
-// kernel is HBM-bound with a factor of two of matrix time in hand, which is what pays for the epilogue VALU, the LDS-DMA issue slots
-// and the statistics reduction.
+//     everybody has finished the previous phase's slot, which is refilled during this phase.  One ds_read_b128 per RW MFMAs.
+//   * The identity is prefetched two chunks ahead into registers, X of the next tile behind the tile's last R phase.
+// Where the memory instructions sit was measured, not assumed (profiles/r05/exp_pair/README.txt, same-box A/B of source variants): LDS-DMA
+// pieces (L2 hits, no register data) are spread over the MFMAs of both phases (issued together behind the barrier they cost 13 %); Z's
+// stores sit between the epilogue's vector instructions and the identity loads follow in a row (stores or loads between MFMAs: + 14 %;
+// stores grouped, loads per unit, pieces in the epilogue, everything spread evenly: + 2 ... 8 %); a software-pipelined form with the
+// epilogue's arithmetic between the R phase's MFMAs was 8 % slower.  At C = 128 / 64 the kernel runs at 5.0-5.4 TB/s (HBM-bound); at C = 256
+// it is bound by instruction ISSUE at one wave per SIMD (matrix pipe 39 % busy, waves stalled at issue 49 % of their cycles, waiting 13 %).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -53,10 +56,10 @@ struct PairArgs {
   const bf16_t* wpack;      // packed W3 | W1 stream (sr_conv_pair_pack)
   const bf16_t* res;        // [M, 4C]  identity
   bf16_t* z;                // [M, 4C]  block output
-  bf16_t* y;                // [M, C]   raw output of the next block's reduce conv
+  bf16_t* y;                // [M, CR]  raw output of the next block's reduce conv
   const float* escale; const float* eshift;      // [4C] bn3 scale / shift
   const float* in_scale; const float* in_shift;  // [C] bn2 scale / shift or null
-  float* stats;             // [grid][2][C]
+  float* stats;             // [grid][2][CR]
   long M;
 };
 
