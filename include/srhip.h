@@ -148,6 +148,7 @@ int sr_conv_stats_rows(const sr_conv_args* a, int dtype);
  *     z[M, Cexp] = relu( (relu(x*in_scale + in_shift) . w_exp[Cexp, Cmid]^T) * escale + eshift + res )      the block's output
  *     y[M, Cred] = z . w_red[Cred, Cexp]^T                                                                   the next block's conv1, RAW
  *     stats      = rows x [2][Cred] partial column sums / sums of squares of y's fp32 accumulators (sr_bn_finalize consumes them)
+ * (eval mode: folded BatchNorms -- y = relu(z . w_red^T + ybias) and no statistics, see `ybias`)
  * in one pass over z: the block output is written once and never read back by the reduce conv (per layer3 block 8.63 -> 6.17 GB of HBM
  * traffic at batch 6144).  x: the RAW output of the bottleneck's 3x3 conv with in_scale / in_shift = its BatchNorm (both NULL: x is
  * already normalised); escale / eshift: bn3's scale / shift (known before the launch: sr_bn_finalize_gram); res: the identity.
@@ -165,10 +166,12 @@ typedef struct sr_pair_args {
   void* z; void* y;
   const float* escale; const float* eshift;
   const float* in_scale; const float* in_shift;
-  float* stats;
+  float* stats;            /* train mode; NULL in eval mode */
+  const float* ybias;      /* eval mode (folded BatchNorm): y = [relu](z . w_red^T + ybias), no statistics; NULL in train mode.  Eval mode
+                              passes the folded weights, escale = ones, eshift = conv3's folded bias, in_scale / in_shift = NULL */
   int64_t M;
   int32_t Cmid, Cexp;
-  int32_t Cred, _pad;      /* output channels of the reduce conv (0 = Cmid) */
+  int32_t Cred, yrelu;     /* Cred: output channels of the reduce conv (0 = Cmid); yrelu: ReLU on y (eval mode) */
 } sr_pair_args;
 int sr_conv_pair_supported(int64_t M, int Cmid, int Cexp, int Cred, int dtype);
 int sr_conv_pair_pack_bytes(int Cmid, int Cexp, int Cred);

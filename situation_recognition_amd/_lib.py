@@ -47,7 +47,8 @@ class ConvArgs(C.Structure):
 class PairArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("wpack", C.c_void_p), ("res", C.c_void_p), ("z", C.c_void_p), ("y", C.c_void_p),
                 ("escale", C.c_void_p), ("eshift", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
-                ("stats", C.c_void_p), ("M", C.c_int64), ("Cmid", C.c_int32), ("Cexp", C.c_int32), ("Cred", C.c_int32), ("_pad", C.c_int32)]
+                ("stats", C.c_void_p), ("ybias", C.c_void_p), ("M", C.c_int64), ("Cmid", C.c_int32), ("Cexp", C.c_int32), ("Cred", C.c_int32),
+                ("yrelu", C.c_int32)]
 
 
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64

@@ -59,7 +59,9 @@ struct PairArgs {
   bf16_t* y;                // [M, CR]  raw output of the next block's reduce conv
   const float* escale; const float* eshift;      // [4C] bn3 scale / shift
   const float* in_scale; const float* in_shift;  // [C] bn2 scale / shift or null
-  float* stats;             // [grid][2][CR]
+  float* stats;             // [grid][2][CR]   (train mode)
+  const float* ybias;       // [CR] eval mode (EV): y = relu?(y + ybias), no statistics
+  int yrelu;
   long M;
 };
 
@@ -145,7 +147,9 @@ __device__ __forceinline__ float prrow16_sum(float v) {
 // base + 8 g + 4 (j & 1) + i: fragments j = 2 t and 2 t + 1 together give the lane columns base + 8 g .. + 7.
 __host__ __device__ constexpr int pair_sigma(int j, int m) { return 32 * (j >> 1) + 8 * (m >> 2) + 4 * (j & 1) + (m & 3); }
 
-template <typename CF, bool IN>
+// IN: X is the RAW output of the 3x3 in front, its BatchNorm + ReLU applied on load (train mode).  EV: eval mode -- Y gets its folded
+// BatchNorm's bias (+ ReLU) instead of partial statistics.
+template <typename CF, bool IN, bool EV>
 __device__ __forceinline__ void pair_body(const PairArgs& p) {
   constexpr int C = CF::C, CX = CF::CX, CR = CF::CR, RW = CF::RW, TM = CF::TM, NCH = CF::NCH, KT = CF::KT, QF = CF::QF, HALF = CF::HALF, PWE = CF::PWE, PWR = CF::PWR;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // escale, eshift | in-affine | 4 statistics rows | weight ring
@@ -165,7 +169,8 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
       inaff[k] = p.in_scale[ch]; inaff[C + k] = p.in_shift[ch];
     }
   }
-  for (int k = lane; k < 2 * CR; k += 64) lstat[k] = 0.f;
+  for (int k = lane; k < 2 * CR; k += 64) lstat[k] = EV ? (wave == 0 && k < CR ? p.ybias[k] : 0.f) : 0.f;   // (EV: wave 0's row holds Y's bias)
+  const float* const ybias = reinterpret_cast<const float*>(smem + CF::STAT);
 
   // ---- weight stream: per chunk EF + RF fragments of 1 KiB (E phase, then R phase), cyclic over the NCH chunks of a tile; of a phase
   // with NP pieces per wave, wave w copies pieces w NP .. w NP + NP - 1
@@ -394,18 +399,28 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] = pracc(yacc[rho][2 * u], i); v[4 + i] = pracc(yacc[rho][2 * u + 1], i); }
+        if constexpr (EV) {
+          const sr_f32x4 b0 = *reinterpret_cast<const sr_f32x4*>(ybias + 32 * u + 8 * g), b1 = *reinterpret_cast<const sr_f32x4*>(ybias + 32 * u + 8 * g + 4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float vm = v[i] * mask[rho];
-          s1[i] += vm;
-          s2[i] = __builtin_fmaf(vm, v[i], s2[i]);
+          for (int i = 0; i < 4; ++i) { v[i] += b0[i]; v[4 + i] += b1[i]; }
+          if (p.yrelu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm("v_max_f32 %0, 0, %1" : "=v"(v[i]) : "v"(v[i]));
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float vm = v[i] * mask[rho];
+            s1[i] += vm;
+            s2[i] = __builtin_fmaf(vm, v[i], s2[i]);
+          }
         }
         bf16_t pk[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) pk[i] = (bf16_t)v[i];
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t*>(pk), srd_y, yo, rho * (16 * CR * 2) + u * 64, 0);
       }
-      if (PAIR_ABL & 16) continue;
+      if (EV || (PAIR_ABL & 16)) continue;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { s1[i] = prrow16_sum(s1[i]); s2[i] = prrow16_sum(s2[i]); }
       if (r == 0) {
@@ -420,16 +435,16 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
   prwait_vm<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  {
+  if constexpr (!EV) {
     const float* const all = reinterpret_cast<const float*>(smem + CF::STAT);
     float* const row = p.stats + (long)blockIdx.x * (2 * CR);
     for (int k = threadIdx.x; k < 2 * CR; k += 256) row[k] = (all[k] + all[2 * CR + k]) + (all[4 * CR + k] + all[6 * CR + k]);
   }
 }
 
-template <typename CF, bool IN>
-__global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(const PairArgs p) { pair_body<CF, IN>(p); }
-template <typename CF, bool IN> struct PairTag {};
+template <typename CF, bool IN, bool EV>
+__global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(const PairArgs p) { pair_body<CF, IN, EV>(p); }
+template <typename CF, bool IN, bool EV> struct PairTag {};
 
 // ---- weight stream: [chunk][EF + RF fragments][lane][8 bf16]: chunk c = the expansion's weights of Z columns 64 c .. + 63 (fragment kk * 4 + j),
 // then K-slice c of the reduce conv (fragment t * QF + q)
@@ -472,17 +487,18 @@ int pair_pack_launch(const void* w_exp, const void* w_red, void* out, hipStream_
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
-template <typename CF, bool IN>
+template <typename CF, bool IN, bool EV>
 int pair_launch_v(const PairArgs& s, unsigned grid, hipStream_t st) {
-  if (!sr_set_dynamic_lds_tagged<PairTag<CF, IN>>(reinterpret_cast<const void*>(&conv1x1_pair_kernel<CF, IN>), CF::LDS)) return SR_ERR_LAUNCH;
-  hipLaunchKernelGGL((conv1x1_pair_kernel<CF, IN>), dim3(grid), dim3(256), CF::LDS, st, s);
+  if (!sr_set_dynamic_lds_tagged<PairTag<CF, IN, EV>>(reinterpret_cast<const void*>(&conv1x1_pair_kernel<CF, IN, EV>), CF::LDS)) return SR_ERR_LAUNCH;
+  hipLaunchKernelGGL((conv1x1_pair_kernel<CF, IN, EV>), dim3(grid), dim3(256), CF::LDS, st, s);
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
 template <typename CF>
 int pair_launch(const PairArgs& s, hipStream_t st) {
   const unsigned grid = pair_grid<CF>(s.M);
-  return s.in_scale ? pair_launch_v<CF, true>(s, grid, st) : pair_launch_v<CF, false>(s, grid, st);
+  if (s.ybias) return pair_launch_v<CF, false, true>(s, grid, st);        // eval mode: X is already normalised (the 3x3's own epilogue)
+  return s.in_scale ? pair_launch_v<CF, true, false>(s, grid, st) : pair_launch_v<CF, false, false>(s, grid, st);
 }
 // one call per configuration: f(PairCfgTag<Cfg>{})
 template <typename CF> struct PairCfgTag { typedef CF type; };
@@ -514,15 +530,17 @@ extern "C" int sr_conv_pair_pack(const void* w_exp, const void* w_red, void* out
   return pair_dispatch(Cmid, Cred, [&](auto tag) { return pair_pack_launch<typename decltype(tag)::type>(w_exp, w_red, out, st); });
 }
 extern "C" int sr_conv_pair(const sr_pair_args* a, int dtype, void* stream) {
-  if (!a || !a->x || !a->wpack || !a->res || !a->z || !a->y || !a->escale || !a->eshift || !a->stats || a->M <= 0) return SR_ERR_ARG;
+  if (!a || !a->x || !a->wpack || !a->res || !a->z || !a->y || !a->escale || !a->eshift || a->M <= 0) return SR_ERR_ARG;
+  if ((a->stats == nullptr) == (a->ybias == nullptr)) return SR_ERR_ARG;        // train mode: statistics; eval mode: Y's bias
   if (dtype != SR_BF16) return SR_ERR_DTYPE;
   if ((a->in_scale == nullptr) != (a->in_shift == nullptr)) return SR_ERR_ARG;
+  if (a->ybias && a->in_scale) return SR_ERR_UNSUPPORTED;
   if (((uintptr_t)a->x | (uintptr_t)a->wpack | (uintptr_t)a->res | (uintptr_t)a->z | (uintptr_t)a->y) & 15) return SR_ERR_ARG;
   const int cred = a->Cred ? a->Cred : a->Cmid;
   if (!pair_shape_ok(a->M, a->Cmid, a->Cexp, cred)) return SR_ERR_UNSUPPORTED;
   PairArgs s;
   s.x = (const bf16_t*)a->x; s.wpack = (const bf16_t*)a->wpack; s.res = (const bf16_t*)a->res; s.z = (bf16_t*)a->z; s.y = (bf16_t*)a->y;
-  s.escale = a->escale; s.eshift = a->eshift; s.in_scale = a->in_scale; s.in_shift = a->in_shift; s.stats = a->stats; s.M = a->M;
+  s.escale = a->escale; s.eshift = a->eshift; s.in_scale = a->in_scale; s.in_shift = a->in_shift; s.stats = a->stats; s.ybias = a->ybias; s.yrelu = a->yrelu; s.M = a->M;
   hipStream_t st = (hipStream_t)stream;
   return pair_dispatch(a->Cmid, cred, [&](auto tag) { return pair_launch<typename decltype(tag)::type>(s, st); });
 }

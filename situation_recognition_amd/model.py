@@ -164,6 +164,21 @@ class _ConvBN:
             self._cache[key] = hit
         return hit[1]
 
+    def pair_pack_folded(self, nxt, dtype, stats_epoch):
+        """The same stream for eval mode: both convolutions with their BatchNorm folded in (`folded`); returns (stream, bias of this
+        unit, bias of `nxt`).  Rebuilt when a weight or the running statistics change."""
+        key = ("pair_fold", dtype)
+        sig = (self._sig(True), nxt._sig(True), stats_epoch)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                w3, b3 = self.folded(dtype, stats_epoch)
+                w1, b1 = nxt.folded(dtype, stats_epoch)
+                hit = (sig, ops.conv_pair_pack(w3.view(self.cout_p, self.cin_p), w1.view(nxt.cout_p, nxt.cin_p)), b3, b1,
+                       torch.ones_like(b3))
+            self._cache[key] = hit
+        return hit[1], hit[2], hit[3], hit[4]
+
     def fp8_eligible(self):
         """3x3 convolutions the e4m3 kernel serves (csrc/fp8.hip): 128 / 256 / 512 input channels, output channels a multiple of 128."""
         return self.k == 3 and self.pad == 1 and self.cin_p in (128, 256, 512) and self.cout_p % 128 == 0 and not self.stem
@@ -345,6 +360,16 @@ class resnet(nn.Module):
                 y = ops.conv3x3_fp8(x, wq, dq, u.cout_p, stride=u.stride)
                 sc, sh = u.eval_affine(self._stats_epoch)
                 return ops.bn_apply(y, sc, sh, res=res, relu=relu, out=y)
+            if pre is not None:                                    # this convolution (+ folded BN + ReLU) ran inside the previous block's fused launch
+                return ops.quantize_fp8(pre[0], self.fp8_act_scale) if quant_out else pre[0]
+            if fuse_next is not None:
+                if res is not None and relu and x.dtype == dt and self._pair_ok(u, fuse_next, x.shape[0] * x.shape[1] * x.shape[2]):
+                    # expansion conv + the next block's reduce conv (both with their BatchNorm folded in) in one pass over the block output
+                    wp, b3, b1, one = u.pair_pack_folded(fuse_next, dt, self._stats_epoch)
+                    z, y1, _ = ops.conv_pair(x, wp, res, one, b3, ybias=b1, yrelu=True)
+                    return z, (y1, None)
+                w, b = u.folded(dt, self._stats_epoch)
+                return ops.conv2d(x, w, u.cout_p, u.k, u.stride, u.pad, bias=b, res=res, relu=relu), None
             w, b = u.folded(dt, self._stats_epoch)
             if self._fused_stem(u, stem_hw, pool_after):           # conv1 + folded BN + ReLU + maxpool in one launch
                 return ops.stem_bn_relu_maxpool(x, w, torch.ones_like(b), b, stem_hw)
@@ -436,11 +461,11 @@ class resnet(nn.Module):
         return ops.bn_apply(y, scale, shift, res=res, relu=relu, out=y)
 
     def _next_reduce(self, bi, train):
-        """The conv1 unit of block bi + 1 when it may run fused with block bi's expansion conv: train mode, both blocks bottlenecks.
+        """The conv1 unit of block bi + 1 when it may run fused with block bi's expansion conv (train and eval mode): both blocks bottlenecks.
         (Across a layer boundary the next block's downsample branch reads block bi's output as well: the output is written either
         way, what the fused launch saves is conv1's read of it.)  Shapes are checked by `_pair_ok`."""
         blocks = self._plan()[1]
-        if not (train and self.fuse_pairs) or bi + 1 >= len(blocks):
+        if not self.fuse_pairs or bi + 1 >= len(blocks):
             return None
         convs, ds = blocks[bi + 1]
         return convs[0] if len(convs) == 3 and len(blocks[bi][0]) == 3 else None

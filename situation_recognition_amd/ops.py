@@ -217,10 +217,11 @@ def conv_pair_pack(w_exp, w_red):
     return out
 
 
-def conv_pair(x, wpack, res, escale, eshift, in_affine=None):
+def conv_pair(x, wpack, res, escale, eshift, in_affine=None, ybias=None, yrelu=True):
     """z = relu((f(x) @ w_exp.T) * escale + eshift + res), y = z @ w_red.T (raw) and y's BatchNorm partials in one launch (sr_conv_pair);
     f = relu(x*in_scale + in_shift) with in_affine, identity without.  x: NHWC [B,H,W,Cmid], res: [B,H,W,Cexp]; the reduce conv's width
-    follows from the weight stream's size.  Returns (z, y [B,H,W,Cred], stats)."""
+    follows from the weight stream's size.  Returns (z, y [B,H,W,Cred], stats).
+    Eval mode (`ybias` [Cred]: the reduce conv's folded BatchNorm bias): y = [relu](z @ w_red.T + ybias), stats is None."""
     require_gpu(x, wpack, res, escale, eshift)
     B, H, W_, Cmid = x.shape
     Cexp = res.shape[3]
@@ -234,7 +235,9 @@ def conv_pair(x, wpack, res, escale, eshift, in_affine=None):
     check(min(rows, 0), "sr_conv_pair_stats_rows")
     z = torch.empty_like(res)
     y = torch.empty((B, H, W_, Cred), device=x.device, dtype=x.dtype)
-    stats = torch.empty((rows, 2, Cred), device=x.device, dtype=torch.float32)
+    stats = None if ybias is not None else torch.empty((rows, 2, Cred), device=x.device, dtype=torch.float32)
+    if ybias is not None and (in_affine is not None or ybias.numel() != Cred):
+        raise L.SrError("conv_pair: eval mode takes no in_affine and a bias of Cred elements")
     a = L.PairArgs()
     a.x, a.wpack, a.res, a.z, a.y = x.data_ptr(), wpack.data_ptr(), res.data_ptr(), z.data_ptr(), y.data_ptr()
     a.escale, a.eshift = _f32(escale, "escale").data_ptr(), _f32(eshift, "eshift").data_ptr()
@@ -243,7 +246,10 @@ def conv_pair(x, wpack, res, escale, eshift, in_affine=None):
         if in_affine[0].numel() != Cmid or in_affine[1].numel() != Cmid:
             raise L.SrError("conv_pair: in_affine must have Cmid elements")
         a.in_scale, a.in_shift = _f32(in_affine[0], "in_scale").data_ptr(), _f32(in_affine[1], "in_shift").data_ptr()
-    a.stats, a.M, a.Cmid, a.Cexp, a.Cred = stats.data_ptr(), M, Cmid, Cexp, Cred
+    a.stats, a.M, a.Cmid, a.Cexp, a.Cred = ptr(stats), M, Cmid, Cexp, Cred
+    if ybias is not None:
+        require_gpu(ybias)
+        a.ybias, a.yrelu = _f32(ybias, "ybias").data_ptr(), int(bool(yrelu))
     flops = 2.0 * M * Cexp * (Cmid + Cred)
     nbytes = 2.0 * (M * Cmid + 2 * M * Cexp + M * Cred + (Cmid + Cred) * Cexp)     # x, res read; z, y written; both weight matrices once
     check(_timed("conv1x1_pair", flops, nbytes, lambda: lib().sr_conv_pair(C.byref(a), L.SR_BF16, stream())), "sr_conv_pair")

@@ -284,3 +284,30 @@ def test_expansion_fused_with_the_next_reduce_conv(world):
     finally:
         net.model.load_state_dict(keep)
         net.eval()
+
+
+def test_eval_mode_expansion_fused_with_the_next_reduce_conv(world):
+    """Eval mode takes the fused launch too (folded BatchNorms; `sr_conv_pair` with a bias + ReLU epilogue on the reduce conv and no
+    statistics): for every pair of layers 1-3 the block output, the next block's conv1 output and the next block continued from it are
+    BIT-IDENTICAL to the unfused launches (which the eval test above holds to the oracle)."""
+    net, acts, ops = world["net"], world["acts"], world["ops"]
+    net.eval()
+    layer_of = [0] * 3 + [1] * 8 + [2] * 36 + [3] * 3
+    fused = 0
+    for bi in range(len(layer_of) - 1):
+        x = batch_from(nhwc(acts[bi][0]), stage_batch(bi), 900 + bi)
+        y, pre = net.block_forward(x, bi, fuse_next=True)
+        if layer_of[bi] == 3 or layer_of[bi + 1] == 3:
+            assert pre is None, bi
+            continue
+        assert pre is not None and pre[1] is None, bi
+        fused += 1
+        y_ref = net.block_forward(x, bi)
+        assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), bi
+        if bi % 5 == 0 or layer_of[bi] < 2:
+            z_ref = net.block_forward(y_ref, bi + 1)
+            z = net.block_forward(y, bi + 1, pre=pre)
+            assert torch.equal(z.view(torch.int16), z_ref.view(torch.int16)), bi
+            del z, z_ref
+        del x, y, y_ref, pre
+    assert fused == 46

@@ -112,6 +112,32 @@ def test_pair_small_and_ragged_row_counts(ops, layer, B):
     assert float(((yf.double() ** 2).sum(0) - s1[1]).abs().max() / s1[1].abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("layer,B", [("layer3", 1024), ("layer2", 301), ("layer1>2", 75)])
+def test_pair_eval_mode_equals_the_two_folded_launches(ops, layer, B):
+    """Eval mode (BatchNorm folded into weights and biases): z = relu(x W3^T + b3 + identity), y = relu(z W1^T + b1), no statistics --
+    bit for bit the weight-stationary expansion launch followed by the generic reduce launch with its bias + ReLU epilogue."""
+    H, C, CR = SHAPES[layer]
+    CX = 4 * C
+    x, res, w3, w1, aff, esc, esh = operands(B, 77, layer)
+    x = torch.relu(x.float() * aff[0] + aff[1]).to(BF)              # (the 3x3's own eval epilogue has normalised its output)
+    b1 = 0.2 * torch.randn(CR, device="cuda")
+    z0 = ops.conv2d(x, w3, CX, 1, 1, 0, bias=esh, res=res, relu=True)
+    y0 = ops.conv2d(z0, w1, CR, 1, 1, 0, bias=b1, relu=True)
+    z1, y1, st = ops.conv_pair(x, ops.conv_pair_pack(w3, w1), res, torch.ones_like(esh), esh, ybias=b1, yrelu=True)
+    assert st is None
+    assert torch.equal(z0.view(torch.int16), z1.view(torch.int16))
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    M = B * H * H
+    rows = torch.cat([torch.arange(0, 256, device="cuda"), torch.arange(M - 256, M, device="cuda")])
+    zr = torch.relu(x.view(M, C)[rows].float() @ w3.float().t() + esh + res.view(M, CX)[rows].float())
+    assert float((zr - z1.view(M, CX)[rows].float()).abs().max()) <= 1.2e-2 * float(zr.abs().max())
+    yr = torch.relu(z1.view(M, CX)[rows].float() @ w1.float().t() + b1)
+    assert float((yr - y1.view(M, CR)[rows].float()).abs().max()) <= 1.2e-2 * float(yr.abs().max())
+    from situation_recognition_amd import _lib
+    with pytest.raises(_lib.SrError):                                # eval mode takes an already normalised x
+        ops.conv_pair(x, ops.conv_pair_pack(w3, w1), res, esc, esh, in_affine=aff, ybias=b1)
+
+
 def test_pair_rejects_what_it_does_not_serve(ops):
     from situation_recognition_amd import _lib
     assert ops.conv_pair_supported(200704, 256, 1024)
