@@ -100,7 +100,8 @@ __device__ __forceinline__ sr_u32x4 sr_affine_relu_chunk(sr_u32x4 v, sr_f32x4 s0
     hi = __builtin_elementwise_fma(hi, sr_f32x2{s[2], s[3]}, sr_f32x2{h[2], h[3]});
     // ReLU AFTER the rounding, on the packed pair: a negative bf16 (including -0) is a negative int16, so max(., 0) as int16 is the
     // ReLU -- rounding is monotonic and keeps the sign, so round(relu(x)) == relu(round(x)) bit for bit (round 5: 20 vector
-    // instructions per chunk instead of 24; every consumer that normalises on load and the Gram sweep share this one function)
+    // instructions per chunk instead of 24; every consumer that normalises on load and the Gram sweep share this one function).
+    // (One difference from v_max_f32: a POSITIVE NaN stays a NaN -- as torch.relu keeps it -- where max(x, 0) returned 0.)
     const sr_bf16x2 w0 = __builtin_convertvector(sr_f32x2{lo[0], hi[0]}, sr_bf16x2), w1 = __builtin_convertvector(sr_f32x2{lo[1], hi[1]}, sr_bf16x2);
     unsigned u0 = __builtin_bit_cast(unsigned, w0), u1 = __builtin_bit_cast(unsigned, w1);
     asm("v_pk_max_i16 %0, %1, 0" : "=v"(u0) : "v"(u0));
