@@ -20,7 +20,7 @@
 //   * X (the tile's rows x C channels per wave) is loaded ONCE per tile into registers in B-operand layout and normalised there
 //     (BatchNorm + ReLU of the 3x3 in front, `sr_affine_relu_chunk`: the same function the unfused expansion kernel applies).
 //   * Z's columns are walked in chunks of 64: E phase (K = C; at C = 256: 8 K-steps x 4 weight fragments x 3 row fragments = 96 MFMAs into
-//     48 accumulator registers), epilogue (scale / shift, + identity, ReLU on the packed pair, bf16, store), R phase (K = 64; 2 K-steps x
+//     48 accumulator registers of the VECTOR file), epilogue (scale / shift, + identity, ReLU on the packed pair, bf16, store), R phase (K = 64; 2 K-steps x
 //     CR / 16 weight fragments x RW MFMAs into Y's accumulators -- 192 AccVGPRs at C = CR = 256 -- which live across all chunks of the tile).
 //   * Only the WEIGHTS go through LDS: both matrices, pre-packed in exactly the order the phases consume them (sr_conv_pair_pack: one
 //     linear stream per tile -- 1 MiB at C = 256 --, a fragment = 1 KiB in lane order, so reads are conflict-free by construction and the
@@ -99,7 +99,10 @@ typedef PairCfg<64, 4> PairL1;         // layer1:  64 ->  256 ->  64 on 56 x 56 
 typedef PairCfg<128, 3, 256> PairL23;  // layer2's last block -> layer3.0.conv1: 128 -> 512 -> 256 on 28 x 28 images
 typedef PairCfg<64, 4, 128> PairL12;   // layer1's last block -> layer2.0.conv1:  64 -> 256 -> 128 on 56 x 56 images
 
-constexpr int NB = 4;                   // weight fragments read ahead of their MFMAs
+#ifndef PAIR_NB
+#define PAIR_NB 4
+#endif
+constexpr int NB = PAIR_NB;             // weight fragments read ahead of their MFMAs (4: measured against 2, 3, 6, 8)
 
 // s_waitcnt vmcnt(N) as the BUILTIN (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt / lgkmcnt left at their maxima): hipcc's own
 // wait insertion sees it and knows which of the loads it tracks (X, the identity) have landed.  Behind an inline-asm wait it cannot see
@@ -126,6 +129,14 @@ __device__ __forceinline__ void prmma0(f32x4_t& acc, const bf16x8_t& w, const bf
 #endif
 }
 
+// the E phase's accumulators live in the VECTOR file (gfx90a+: an MFMA's C / D may be either file): the epilogue reads every element once,
+// and with one wave per SIMD the 768 v_accvgpr_read per tile were plain issue time (round 5: 231 VGPR + 192 AccVGPR, - 1.3 % at layer3)
+__device__ __forceinline__ void prmmav(f32x4_t& acc, const bf16x8_t& w, const bf16x8_t& b) {
+  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+}
+__device__ __forceinline__ void prmmav0(f32x4_t& acc, const bf16x8_t& w, const bf16x8_t& b) {
+  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(w), "v"(b));
+}
 // element i of an accumulator fragment as a vector register (explicit: asked for the values in plain C++, hipcc moves whole fragments
 // from the accumulator file to the vector file THROUGH SCRATCH once both files are full)
 __device__ __forceinline__ float pracc(const f32x4_t& acc, int i) {
@@ -291,8 +302,8 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rho = 0; rho < RW; ++rho) {
-          if (kk == 0) prmma0(zacc[rho][j], wf[f % NB], __builtin_bit_cast(bf16x8_t, a[rho][kk]));
-          else prmma(zacc[rho][j], wf[f % NB], __builtin_bit_cast(bf16x8_t, a[rho][kk]));
+          if (kk == 0) prmmav0(zacc[rho][j], wf[f % NB], __builtin_bit_cast(bf16x8_t, a[rho][kk]));
+          else prmmav(zacc[rho][j], wf[f % NB], __builtin_bit_cast(bf16x8_t, a[rho][kk]));
         }
         __builtin_amdgcn_sched_barrier(0);
         if (f + NB < CF::EF) wf[f % NB] = *reinterpret_cast<const bf16x8_t*>(es + (f + NB) * 1024);
@@ -315,15 +326,15 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
           float v[8];
           if (PAIR_ABL & 8) {
             u32x4_t keep = a[rho][t] ^ iv;                 // (one read per accumulator fragment keeps the E phase alive)
-            keep[0] ^= __float_as_uint(pracc(zacc[rho][2 * t], 0)) ^ __float_as_uint(pracc(zacc[rho][2 * t + 1], 0));
+            keep[0] ^= __float_as_uint(zacc[rho][2 * t][0]) ^ __float_as_uint(zacc[rho][2 * t + 1][0]);
             zb[rho][t] = __builtin_bit_cast(bf16x8_t, keep);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, zb[rho][t]), srd_z, zo, PR_ZOFF(rho, c, t), 0);
             continue;
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            v[i] = __builtin_fmaf(pracc(zacc[rho][2 * t], i), s0[i], h0[i]);
-            v[4 + i] = __builtin_fmaf(pracc(zacc[rho][2 * t + 1], i), s1[i], h1[i]);
+            v[i] = __builtin_fmaf(zacc[rho][2 * t][i], s0[i], h0[i]);
+            v[4 + i] = __builtin_fmaf(zacc[rho][2 * t + 1][i], s1[i], h1[i]);
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
