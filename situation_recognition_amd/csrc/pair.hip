@@ -137,13 +137,6 @@ __device__ __forceinline__ void prmmav(f32x4_t& acc, const bf16x8_t& w, const bf
 __device__ __forceinline__ void prmmav0(f32x4_t& acc, const bf16x8_t& w, const bf16x8_t& b) {
   asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(w), "v"(b));
 }
-// (pair2: the B operand -- the X tile -- lives in the accumulator file: at two waves per SIMD hipcc gives each file half of the 256 registers)
-__device__ __forceinline__ void prmmav_ba(f32x4_t& acc, const bf16x8_t& w, const u32x4_t& b) {
-  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(b));
-}
-__device__ __forceinline__ void prmmav0_ba(f32x4_t& acc, const bf16x8_t& w, const u32x4_t& b) {
-  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(w), "a"(b));
-}
 // element i of an accumulator fragment as a vector register (explicit: asked for the values in plain C++, hipcc moves whole fragments
 // from the accumulator file to the vector file THROUGH SCRATCH once both files are full)
 __device__ __forceinline__ float pracc(const f32x4_t& acc, int i) {
@@ -460,280 +453,6 @@ __device__ __forceinline__ void pair_body(const PairArgs& p) {
   }
 }
 
-// =====================================================================================================
-// Layer3 form with TWO waves per SIMD (C = CR = 256, train mode).  The kernel above is bound by instruction issue: with one wave per SIMD
-// every vector / memory instruction of the epilogues is issued with the matrix pipe idle.  Here a workgroup has 8 waves (256 registers
-// each): the 128-row tile is split into 4 row groups of 32 rows (RW = 2), and the two waves of a row group -- h = 0 / 1, on the SAME SIMD --
-// split the COLUMNS: wave h computes Z's columns 32 h .. + 31 of every chunk (2 of the 4 weight fragments per K-step), runs their epilogue
-// (scale / shift, identity, ReLU, store), hands its 16-byte operand pieces to its partner through a 2 KiB LDS strip, and accumulates Y's
-// columns 128 h .. + 127 over BOTH halves of the chunk (t = 0, 1 in this order: the summation order of the unfused kernel).  Registers per
-// wave: X 64, Z accumulators 16, identity 16, Z operand 16, fragments 16, Y 64 (AccVGPRs).  Same packed weight stream, same ring (a
-// phase's 32 pieces are 4 per wave), same two barriers per chunk (the R phase's barrier also publishes the partner's Z pieces).  LDS:
-// tables 8 KiB | statistics 8 x 1 KiB | exchange 8 x 2 KiB | ring 4 x 32 KiB = 160 KiB exactly; the input BatchNorm's scale / shift have
-// no room of their own and are reloaded into the exchange strip at every tile start (two more barriers per tile).
-// =====================================================================================================
-struct Pair2 {
-  static constexpr int C = 256, CX = 1024, CR = 256, RW = 2, TM = 128, NCH = 16, KT = 8, QF = 16;
-  static constexpr int EF = 32, RF = 32, HALF = 32 * 1024, CHB = 64 * 1024, PW = 4;
-  static constexpr int TAB = 0, STAT = 8192, XCH = 16384, RING = 32768, LDS = RING + 4 * HALF;
-  static constexpr int ST = RW, LD = RW, YST = RW * 4;
-  static constexpr int NE = PW + ST + LD + PW, NR = ST + LD + PW + PW + ST + LD, NI = 4 * PW + ST + LD, NA = YST;
-  static_assert(LDS == 160 * 1024, "pair2 LDS budget");
-};
-
-template <bool IN>
-__device__ __forceinline__ void pair2_body(const PairArgs& p) {
-  typedef Pair2 CF;
-  constexpr int C = CF::C, CX = CF::CX, CR = CF::CR, RW = CF::RW, TM = CF::TM, NCH = CF::NCH, KT = CF::KT, HALF = CF::HALF, PW = CF::PW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int rgp = wave & 3, h = wave >> 2;                 // row group, column half (partner = wave ^ 4: waves w and w + 4 share a SIMD)
-  const int r = lane & 15, g = lane >> 4;
-  const long ntiles = (p.M + TM - 1) / TM;
-  const int G = gridDim.x;
-
-  float* const tab = reinterpret_cast<float*>(smem + CF::TAB);
-  float* const inaff = reinterpret_cast<float*>(smem + CF::XCH);            // (tile start only: see above)
-  float* const lstat = reinterpret_cast<float*>(smem + CF::STAT) + wave * 256;   // [2][128]: this wave's 128 Y columns
-  for (int k = threadIdx.x; k < CX; k += 512) { tab[k] = p.escale[k]; tab[CX + k] = p.eshift[k]; }
-  for (int k = lane; k < 256; k += 64) lstat[k] = 0.f;
-
-  const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpack, 0, NCH * CF::CHB, 0x00020000);
-  const int w_lane = lane * 16;
-  auto issue_w1 = [&](int slot, int kind, int c, int i) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (__attribute__((address_space(3))) void*)(smem + CF::RING + slot * HALF + (wave * PW + i) * 1024), 16, w_lane,
-                                             c * CF::CHB + (kind ? CF::EF * 1024 : 0) + (wave * PW + i) * 1024, 0, 0);
-  };
-  auto issue_w = [&](int slot, int kind, int c) {
-#pragma unroll
-    for (int i = 0; i < PW; ++i) issue_w1(slot, kind, c, i);
-  };
-  auto wave_rows = [&](long tile) -> long {
-    if (tile >= ntiles) return 0;
-    const long left = p.M - (tile * TM + rgp * (16 * RW));
-    return left < 0 ? 0 : (left > 16 * RW ? 16 * RW : left);
-  };
-  auto srd_of = [&](const bf16_t* base, long tile, int ld) {
-    const long rows = wave_rows(tile);
-    const long m0 = rows > 0 ? tile * TM + rgp * (16 * RW) : 0;
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + m0 * ld), 0, (int)(rows * ld * 2), 0x00020000);
-  };
-  const int xo = r * (C * 2) + g * 16;                     // + rho * 16 * C * 2 + kk * 64
-  const int zo = r * (CX * 2) + g * 16 + h * 64;           // + rho * 16 * CX * 2 + 128 c      (this wave's 32 columns of the chunk)
-
-  u32x4_t a[RW][KT];
-  auto load_a = [&](long tile) {
-    const __amdgpu_buffer_rsrc_t s = srd_of(p.x, tile, C);
-#pragma unroll
-    for (int kk = 0; kk < KT; ++kk)
-#pragma unroll
-      for (int rho = 0; rho < RW; ++rho) a[rho][kk] = __builtin_amdgcn_raw_buffer_load_b128(s, xo, rho * (16 * C * 2) + kk * 64, 0);
-  };
-  u32x4_t idn[2][RW];
-  auto load_idn = [&](auto BUF, const __amdgpu_buffer_rsrc_t s, int c) {
-    constexpr int buf = decltype(BUF)::value;
-#pragma unroll
-    for (int rho = 0; rho < RW; ++rho) idn[buf][rho] = __builtin_amdgcn_raw_buffer_load_b128(s, zo, rho * (16 * CX * 2) + 128 * c, 0);
-  };
-  const unsigned xch_own = (unsigned)(uintptr_t)(smem + CF::XCH + wave * 2048 + lane * 16);
-  const char* const xch_rd = smem + CF::XCH + rgp * 2048 + lane * 16;      // + t * 8192 (wave 4 t + rgp) + rho * 1024
-
-  f32x4_t yacc[RW][8];                                     // Y^T fragments q = 8 h + qq
-
-  long tile = blockIdx.x;
-  issue_w(0, 0, 0);
-  issue_w(1, 1, 0);
-  issue_w(2, 0, 1);
-  load_a(tile);
-  {
-    const __amdgpu_buffer_rsrc_t s = srd_of(p.res, tile, CX);
-    load_idn(std::integral_constant<int, 0>{}, s, 0);
-    load_idn(std::integral_constant<int, 1>{}, s, 1);
-  }
-  prwait_vm<0>();
-  __syncthreads();
-
-  for (; tile < ntiles; tile += G) {
-    const long tnext = tile + G;
-    const __amdgpu_buffer_rsrc_t srd_z = srd_of(p.z, tile, CX);
-    const __amdgpu_buffer_rsrc_t srd_rc = srd_of(p.res, tile, CX), srd_rn = srd_of(p.res, tnext, CX);
-    prwait_vm<CF::NA>();
-    if (IN) {
-      // the exchange strip is free (everybody is past the last R phase's reads): the input BatchNorm's scale / shift, pair order
-      __builtin_amdgcn_s_barrier();
-      {
-        const int k = threadIdx.x & 255, ch = (k & ~7) | sr_pair_order(k & 7);
-        const float v = threadIdx.x < 256 ? p.in_scale[ch] : p.in_shift[ch];
-        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"((unsigned)(uintptr_t)(inaff + threadIdx.x)), "v"(v) : "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      int z;
-      asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-#pragma unroll
-      for (int kk = 0; kk < KT; ++kk) {
-        const int c8 = kk * 32 + (g + z) * 8;
-        const sr_f32x4 s0 = *reinterpret_cast<const sr_f32x4*>(inaff + c8), s1 = *reinterpret_cast<const sr_f32x4*>(inaff + c8 + 4);
-        const sr_f32x4 h0 = *reinterpret_cast<const sr_f32x4*>(inaff + C + c8), h1 = *reinterpret_cast<const sr_f32x4*>(inaff + C + c8 + 4);
-#pragma unroll
-        for (int rho = 0; rho < RW; ++rho) a[rho][kk] = sr_affine_relu_chunk(a[rho][kk], s0, s1, h0, h1);
-      }
-    }
-
-    auto chunk = [&](auto PARC, auto FIRSTC, const int c) {
-      constexpr int PAR = decltype(PARC)::value;
-      constexpr bool FIRST = decltype(FIRSTC)::value;
-      constexpr int SE = 2 * PAR, SR = 2 * PAR + 1;
-      // ---------------- E phase: zacc[rho][jj] = W3 fragment (kk, 2 h + jj) x X[rho][kk]
-      prwait_vm<CF::NE>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const int c_e = c + 1 >= NCH ? c + 1 - NCH : c + 1;
-      f32x4_t zacc[RW][2];
-      const char* const es = smem + CF::RING + SE * HALF + lane * 16 + h * 2048;
-      bf16x8_t wf[NB];
-#pragma unroll
-      for (int f = 0; f < NB; ++f) wf[f] = *reinterpret_cast<const bf16x8_t*>(es + ((f / 2) * 4 + (f % 2)) * 1024);
-#pragma unroll
-      for (int f = 0; f < 16; ++f) {
-        const int kk = f / 2, jj = f % 2;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rho = 0; rho < RW; ++rho) {
-          zacc[rho][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f % NB], __builtin_bit_cast(bf16x8_t, a[rho][kk]), kk == 0 ? f32x4_t{0.f, 0.f, 0.f, 0.f} : zacc[rho][jj], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (f + NB < 16) wf[f % NB] = *reinterpret_cast<const bf16x8_t*>(es + (((f + NB) / 2) * 4 + ((f + NB) % 2)) * 1024);
-        if (f % 4 == 2) issue_w1((SE + 3) & 3, 1, c_e, f / 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---------------- epilogue of this wave's 32 columns; the operand pieces go to the exchange strip
-      prwait_vm<CF::NI>();
-      {
-        const int col = 64 * c + 32 * h + 8 * g;
-        const sr_f32x4 s0 = *reinterpret_cast<const sr_f32x4*>(tab + col), s1 = *reinterpret_cast<const sr_f32x4*>(tab + col + 4);
-        const sr_f32x4 h0 = *reinterpret_cast<const sr_f32x4*>(tab + CX + col), h1 = *reinterpret_cast<const sr_f32x4*>(tab + CX + col + 4);
-#pragma unroll
-        for (int rho = 0; rho < RW; ++rho) {
-          const u32x4_t iv = idn[PAR][rho];
-          float v[8];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = __builtin_fmaf(zacc[rho][0][i], s0[i], h0[i]);
-            v[4 + i] = __builtin_fmaf(zacc[rho][1][i], s1[i], h1[i]);
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[2 * k] += __uint_as_float(iv[k] << 16);
-            v[2 * k + 1] += __uint_as_float(iv[k] & 0xffff0000u);
-          }
-          sr_u32x4 pk;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            pk[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(sr_f32x2{v[2 * k], v[2 * k + 1]}, sr_bf16x2));
-            asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk[k]) : "v"(pk[k]));
-          }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pk), srd_z, zo, rho * (16 * CX * 2) + 128 * c, 0);
-          asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(xch_own), "v"(pk), "n"(rho * 1024) : "memory");
-        }
-      }
-      if (c + 2 < NCH) load_idn(PARC, srd_rc, c + 2);
-      else load_idn(PARC, srd_rn, c + 2 - NCH);
-      // ---------------- R phase: yacc[rho][qq] += W1 fragment (t, 8 h + qq) x Z[rho][t], t = 0 then 1 (pieces of both waves of the row group)
-      prwait_vm<CF::NR>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const int c_r = c + 2 >= NCH ? c + 2 - NCH : c + 2;
-      bf16x8_t zb[RW][2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int rho = 0; rho < RW; ++rho) zb[rho][t] = *reinterpret_cast<const bf16x8_t*>(xch_rd + t * 8192 + rho * 1024);
-      const char* const rs = smem + CF::RING + SR * HALF + lane * 16 + h * 8192;
-#pragma unroll
-      for (int f = 0; f < NB; ++f) wf[f] = *reinterpret_cast<const bf16x8_t*>(rs + ((f / 8) * 16 + (f % 8)) * 1024);
-#pragma unroll
-      for (int f = 0; f < 16; ++f) {
-        const int t = f / 8, qq = f % 8;
-        __builtin_amdgcn_sched_barrier(0);
-        if (FIRST && t == 0) {
-#pragma unroll
-          for (int rho = 0; rho < RW; ++rho) yacc[rho][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f % NB], zb[rho][t], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int rho = 0; rho < RW; ++rho) yacc[rho][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f % NB], zb[rho][t], yacc[rho][qq], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (f + NB < 16) wf[f % NB] = *reinterpret_cast<const bf16x8_t*>(rs + (((f + NB) / 8) * 16 + ((f + NB) % 8)) * 1024);
-        if (f % 4 == 2) issue_w1((SR + 3) & 3, 0, c_r, f / 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    chunk(std::integral_constant<int, 0>{}, std::true_type{}, 0);
-    chunk(std::integral_constant<int, 1>{}, std::false_type{}, 1);
-    for (int cp = 1; cp < NCH / 2; ++cp) {
-      chunk(std::integral_constant<int, 0>{}, std::false_type{}, 2 * cp);
-      chunk(std::integral_constant<int, 1>{}, std::false_type{}, 2 * cp + 1);
-    }
-    load_a(tnext);
-
-    // ---------------- Y epilogue: this wave's columns 128 h .. + 127
-    const __amdgpu_buffer_rsrc_t srd_y = srd_of(p.y, tile, CR);
-    const long row0 = tile * TM + rgp * (16 * RW) + r;
-    float mask[RW];
-#pragma unroll
-    for (int rho = 0; rho < RW; ++rho) mask[rho] = row0 + 16 * rho < p.M ? 1.f : 0.f;
-    unsigned stat_at;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(stat_at) : "v"((unsigned)(uintptr_t)(lstat + 8 * g)));
-    const int yo = r * (CR * 2) + g * 16 + h * 256;         // + rho * 16 * CR * 2 + uu * 64
-#pragma unroll
-    for (int uu = 0; uu < 4; ++uu) {
-      float s1[8], s2[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-#pragma unroll
-      for (int rho = 0; rho < RW; ++rho) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = yacc[rho][2 * uu][i]; v[4 + i] = yacc[rho][2 * uu + 1][i]; }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float vm = v[i] * mask[rho];
-          s1[i] += vm;
-          s2[i] = __builtin_fmaf(vm, v[i], s2[i]);
-        }
-        bf16_t pk[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pk[i] = (bf16_t)v[i];
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t*>(pk), srd_y, yo, rho * (16 * CR * 2) + uu * 64, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { s1[i] = prrow16_sum(s1[i]); s2[i] = prrow16_sum(s2[i]); }
-      if (r == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          asm volatile("ds_add_f32 %0, %1 offset:%3\n\tds_add_f32 %0, %2 offset:%4" ::"v"(stat_at), "v"(s1[i]), "v"(s2[i]), "n"((32 * uu + i) * 4), "n"(512 + (32 * uu + i) * 4) : "memory");
-      }
-    }
-  }
-  prwait_vm<0>();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();
-  {
-    // statistics row [2][CR]: entry (which, col) = the four row groups' sums of column col (wave 4 (col / 128) + rgp), fixed order
-    const float* const all = reinterpret_cast<const float*>(smem + CF::STAT);
-    const int k = threadIdx.x, which = k >> 8, col = k & 255, hh = col >> 7, cl = col & 127;
-    const float* const s = all + (hh * 4) * 256 + which * 128 + cl;
-    p.stats[(long)blockIdx.x * (2 * CR) + k] = (s[0] + s[256]) + (s[512] + s[768]);
-  }
-}
-
-template <bool IN>
-__global__ __launch_bounds__(512, 1) void conv1x1_pair2_kernel(const PairArgs p) { pair2_body<IN>(p); }
-template <bool IN> struct Pair2Tag {};
-
 template <typename CF, bool IN, bool EV>
 __global__ __launch_bounds__(256, 1) void conv1x1_pair_kernel(const PairArgs p) { pair_body<CF, IN, EV>(p); }
 template <typename CF, bool IN, bool EV> struct PairTag {};
@@ -786,28 +505,8 @@ int pair_launch_v(const PairArgs& s, unsigned grid, hipStream_t st) {
   SR_CHECK_LAUNCH();
   return SR_OK;
 }
-// layer3, train mode: the two-waves-per-SIMD form, OFF by default (measured slower than the four-wave kernel: profiles/r05/exp_pair/README.txt);
-// SR_PAIR2=1 selects it for the A/B
-inline bool pair2_enabled() {
-  static const bool on = [] { const char* e = getenv("SR_PAIR2"); return e && e[0] == '1'; }();
-  return on;
-}
-inline unsigned pair2_grid(long M) {
-  const long ntiles = (M + Pair2::TM - 1) / Pair2::TM, cus = sr_num_cus();
-  return (unsigned)(ntiles < cus ? ntiles : cus);
-}
-template <bool IN>
-int pair2_launch_v(const PairArgs& s, hipStream_t st) {
-  if (!sr_set_dynamic_lds_tagged<Pair2Tag<IN>>(reinterpret_cast<const void*>(&conv1x1_pair2_kernel<IN>), Pair2::LDS)) return SR_ERR_LAUNCH;
-  hipLaunchKernelGGL((conv1x1_pair2_kernel<IN>), dim3(pair2_grid(s.M)), dim3(512), Pair2::LDS, st, s);
-  SR_CHECK_LAUNCH();
-  return SR_OK;
-}
 template <typename CF>
 int pair_launch(const PairArgs& s, hipStream_t st) {
-  if constexpr (CF::C == 256 && CF::CR == 256) {
-    if (!s.ybias && pair2_enabled()) return s.in_scale ? pair2_launch_v<true>(s, st) : pair2_launch_v<false>(s, st);
-  }
   const unsigned grid = pair_grid<CF>(s.M);
   if (s.ybias) return pair_launch_v<CF, false, true>(s, grid, st);        // eval mode: X is already normalised (the 3x3's own epilogue)
   return s.in_scale ? pair_launch_v<CF, true, false>(s, grid, st) : pair_launch_v<CF, false, false>(s, grid, st);
@@ -831,7 +530,6 @@ extern "C" int sr_conv_pair_pack_bytes(int Cmid, int Cexp, int Cred) {
 }
 extern "C" int sr_conv_pair_stats_rows(int64_t M, int Cmid, int Cexp, int Cred) {
   if (!pair_shape_ok(M, Cmid, Cexp, Cred)) return SR_ERR_UNSUPPORTED;
-  if (Cmid == 256 && Cred == 256 && pair2_enabled()) return (int)pair2_grid(M);
   return (int)pair_dispatch(Cmid, Cred, [&](auto tag) { return pair_grid<typename decltype(tag)::type>(M); });
 }
 extern "C" int sr_conv_pair_pack(const void* w_exp, const void* w_red, void* out, int Cmid, int Cexp, int Cred, int dtype, void* stream) {
